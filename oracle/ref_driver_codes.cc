@@ -1,0 +1,37 @@
+/*
+ * ref_driver_codes.cc -- C-linkage callers for the reference's PRN generators
+ * (test infrastructure).  gps_sdr_signal_processing.cc and
+ * beidou_b1i_signal_processing.cc are compiled from /root/reference where they
+ * lie (oracle/Makefile target `ref`); this file only gives them C names.
+ */
+#ifdef REF_BDS
+#include "beidou_b1i_signal_processing.h"
+#endif
+#ifdef REF_GPS
+#include "gps_sdr_signal_processing.h"
+#endif
+#include <complex>
+#include <cstdint>
+
+extern "C" {
+#ifdef REF_GPS
+void ref_gps_l1_ca_code_gen_int(int32_t* dest, int32_t prn, uint32_t chip_shift)
+{
+    gps_l1_ca_code_gen_int(dest, prn, chip_shift);
+}
+void ref_gps_l1_ca_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift)
+{
+    gps_l1_ca_code_gen_complex_sampled(reinterpret_cast<std::complex<float>*>(dest), prn, fs, chip_shift);
+}
+#endif
+#ifdef REF_BDS
+void ref_beidou_b1i_code_gen_int(int32_t* dest, int32_t prn, uint32_t chip_shift)
+{
+    beidou_b1i_code_gen_int(dest, prn, chip_shift);
+}
+void ref_beidou_b1i_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift)
+{
+    beidou_b1i_code_gen_complex_sampled(reinterpret_cast<std::complex<float>*>(dest), prn, fs, chip_shift);
+}
+#endif
+}

@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X correlator engine.
+
+Metric (BASELINE.json): Msamples/s tracked by the N-channel multicorrelator
+(+ acquisition dwells/s, + achieved HBM-bandwidth fraction).
+
+Workload at N=1 (BASELINE.json configs[1]): GPS L1 C/A, 32 channels, 25 Msps,
+3-tap E/P/L multicorrelator, one code period (25000 samples) per channel-epoch.
+A "step" = one pass of the tracking hot path over one batch: 32 channels x
+EPOCHS epochs, i.e. ONE launch of the batched kernel, with IQ, per-epoch
+parameters and code tables already resident in HBM.  Every channel reads its
+OWN IQ buffer ("distinct-input" mode) so that the
+algorithmic bytes (8 B per channel-sample) are real HBM traffic and the HBM
+roofline is meaningful; the shared-stream figure (all 32 channels on one RF
+stream, served from L2 / Infinity Cache) is reported beside it, not as `value`.
+
+Multi-GPU (driver: python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...): channels shard over ranks (32 per GPU, BASELINE configs[4]), no
+data-path collective; RCCL is used only for the barrier and the max-over-ranks
+of the elapsed time.  scaling = "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "gnss-sdr-1_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+
+FS = 25_000_000
+N_EPOCH = 25000          # samples per code period at 25 Msps
+N_CHANNELS = 32          # per GPU
+N_TAPS = 3
+CODE_LEN = 1023
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def gps_ca_code(prn):
+    """GPS L1 C/A code (IS-GPS-200 G1/G2 generators), +-1 floats.  Bench-local
+    generator so that the timed path does not depend on the oracle."""
+    taps = {1: (2, 6), 2: (3, 7), 3: (4, 8), 4: (5, 9), 5: (1, 9), 6: (2, 10), 7: (1, 8), 8: (2, 9), 9: (3, 10),
+        10: (2, 3), 11: (3, 4), 12: (5, 6), 13: (6, 7), 14: (7, 8), 15: (8, 9), 16: (9, 10), 17: (1, 4), 18: (2, 5),
+        19: (3, 6), 20: (4, 7), 21: (5, 8), 22: (6, 9), 23: (1, 3), 24: (4, 6), 25: (5, 7), 26: (6, 8), 27: (7, 9),
+        28: (8, 10), 29: (1, 6), 30: (2, 7), 31: (3, 8), 32: (4, 9)}
+    g1 = [1] * 10
+    g2 = [1] * 10
+    a, b = taps[prn]
+    out = np.empty(1023, np.float32)
+    for i in range(1023):
+        chip = g1[9] ^ g2[a - 1] ^ g2[b - 1]
+        out[i] = 1.0 if chip else -1.0
+        f1 = g1[2] ^ g1[9]
+        f2 = g2[1] ^ g2[2] ^ g2[5] ^ g2[7] ^ g2[8] ^ g2[9]
+        g1 = [f1] + g1[:9]
+        g2 = [f2] + g2[:9]
+    return out
+
+
+def make_channel_stream(torch, dev, code, n_samples, seed):
+    """Seeded synthetic IQ for one channel: unit-variance complex noise + one
+    PRN at C/N0 in [38, 48] dB-Hz, Doppler in +-5 kHz."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cn0 = rng.uniform(38.0, 48.0)
+    amp = float(np.sqrt(10.0 ** (cn0 / 10.0) / FS))
+    fd = float(rng.uniform(-5000.0, 5000.0))
+    tau0 = float(rng.uniform(0, CODE_LEN))
+    phi = float(rng.uniform(0, 2 * np.pi))
+    rate = 1.023e6 * (1.0 + fd / 1575.42e6)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.randn(n_samples, 2, device=dev, generator=g, dtype=torch.float32) * float(np.sqrt(0.5))
+    n = torch.arange(n_samples, device=dev, dtype=torch.float64)
+    chip = torch.floor(tau0 + n * (rate / FS)).to(torch.int64) % CODE_LEN
+    c = torch.from_numpy(code).to(dev)[chip]
+    ph = (2 * np.pi * fd / FS) * n + phi
+    x[:, 0] += (amp * c * torch.cos(ph).to(torch.float32))
+    x[:, 1] += (amp * c * torch.sin(ph).to(torch.float32))
+    truth = dict(amp=amp, doppler=fd, tau0=tau0, phi=phi, code_rate=rate)
+    return x.contiguous(), truth
+
+
+def epoch_records(gnsscorr, truth, n_epochs):
+    """Open-loop per-epoch arguments as do_correlation_step would pass them
+    (dll_pll_veml_tracking.cc:886-897), one window per code period."""
+    recs = []
+    step = truth["code_rate"] / FS
+    for k in range(n_epochs):
+        start = k * N_EPOCH
+        code_phase = (truth["tau0"] + start * step) % CODE_LEN
+        rem = -code_phase
+        if rem < -CODE_LEN / 2:
+            rem += CODE_LEN
+        carr = (truth["phi"] + 2 * np.pi * truth["doppler"] * start / FS) % (2 * np.pi)
+        recs.append(gnsscorr.epoch_params(start, float(np.float32(carr)), float(np.float32(2 * np.pi * truth["doppler"] / FS)),
+            float(np.float32(rem)), float(np.float32(step)), N_EPOCH))
+    return recs
+
+
+def cpu_baseline(codes_np, shifts, sample_sig, sample_recs, budget_s):
+    """The oracle (validated CPU restatement of the volk_gnsssdr generic path,
+    -O3 -march=native, 1 thread) timed on a bounded sample of the same workload."""
+    from oracle import Oracle
+    orc = Oracle(native=True)
+    sig = sample_sig
+    n_done = 0
+    t0 = time.perf_counter()
+    while True:
+        for rec in sample_recs:
+            # same scalars the GPU epoch was built from
+            orc.multicorrelator(sig[rec[0]:], codes_np, shifts, rec[1], rec[2], rec[3], rec[4], N_EPOCH)
+            n_done += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return n_done * N_EPOCH / dt / 1e6, n_done, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--epochs", type=int, default=256, help="code periods per channel per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-acq", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gnsscorr
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = gnsscorr.Context(local_rank)
+    E = args.epochs
+    n_stream = E * N_EPOCH + 64
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    # channel c of rank r tracks PRN ((r*32 + c) % 32) + 1 on its own IQ buffer
+    streams, params, truths, codes = [], [], [], []
+    batch = gnsscorr.TrackingBatch(ctx, N_CHANNELS, N_TAPS, CODE_LEN)
+    for ch in range(N_CHANNELS):
+        prn = (rank * N_CHANNELS + ch) % 32 + 1
+        code = gps_ca_code(prn)
+        x, truth = make_channel_stream(torch, dev, code, n_stream, seed=1002 + 1000 * rank + ch)
+        streams.append(x)
+        truths.append(truth)
+        codes.append(code)
+        batch.set_code(ch, code, shifts)
+        batch.set_input_dev(ch, x.data_ptr(), n_stream)
+        params.append(epoch_records(gnsscorr, truth, E))
+    batch.set_nominal_length(N_EPOCH)
+    h_params = gnsscorr.epoch_params_array(params)
+    d_params = torch.from_numpy(h_params.view(np.uint8)).to(dev)
+    d_out = torch.zeros(N_CHANNELS * E * N_TAPS, 2, device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        batch.run_dev(E, d_params.data_ptr(), d_out.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t.item())
+    torch.cuda.synchronize()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    samples_per_step = N_CHANNELS * E * N_EPOCH  # per GPU
+    value = samples_per_step * world * args.steps / elapsed / 1e6
+    alg_bytes = 8.0 * samples_per_step
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    # sanity: the prompt correlators see their signals (guards against timing a broken path)
+    out = d_out.cpu().numpy().reshape(N_CHANNELS, E, N_TAPS, 2)
+    pmag = np.hypot(out[:, :, 1, 0], out[:, :, 1, 1]).mean(axis=1)
+    expect = np.array([t["amp"] * N_EPOCH for t in truths])
+    assert np.all(pmag > 0.5 * expect), "prompt correlators lost the signal"
+
+    result = None
+    if rank == 0:
+        extra = {}
+        # ---- shared-stream mode: all 32 channels on ONE RF stream (cache-served) ----
+        for ch in range(N_CHANNELS):
+            batch.set_input_dev(ch, streams[0].data_ptr(), n_stream)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(args.steps):
+            step()
+        s1.record()
+        torch.cuda.synchronize()
+        shared_ms = s0.elapsed_time(s1) / args.steps
+        extra["shared_stream"] = {"value": samples_per_step / (shared_ms * 1e-3) / 1e6, "unit": "Msamples/s",
+            "ms_per_step": shared_ms, "note": "32 channels read one RF stream; input served from L2/Infinity Cache"}
+        extra["realtime_factor_256ch"] = value / world / (256 * FS / 1e6)
+
+        # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----
+        if not args.no_acq:
+            acq = gnsscorr.PcpsAcquisition(ctx, 32, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,
+                5000, 250, max_dwells=2, use_cfar=False, num_doppler_bins_override=41)
+            for s in range(32):
+                code = gps_ca_code(s + 1)
+                idx = np.minimum((np.arange(N_EPOCH) * (1.023e6 / FS)).astype(np.int64), 1022)
+                acq.set_local_code(s, code[idx].astype(np.complex64))
+            x = streams[0]
+            def acq_search():
+                acq.reset()
+                acq.dwell_enqueue(x.data_ptr(), stream)
+                acq.dwell_enqueue(x.data_ptr() + 8 * N_EPOCH, stream)
+            acq_search()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            a0.record()
+            for _ in range(reps):
+                acq_search()
+            a1.record()
+            torch.cuda.synchronize()
+            acq_ms = a0.elapsed_time(a1) / reps
+            extra["acquisition"] = {"dwells_per_s": 64 / (acq_ms * 1e-3), "ms_per_search": acq_ms,
+                "workload": "GPS L1 C/A PCPS, 25 Msps, N=25000, 32 PRNs x 41 Doppler bins x 2 dwells"}
+            acq.close()
+
+        cpu = None
+        if not args.no_cpu and world == 1:
+            sig0 = streams[0].cpu().numpy().view(np.complex64).reshape(-1)
+            t = truths[0]
+            step_c = t["code_rate"] / FS
+            recs = []
+            for k in range(min(E, 64)):
+                start = k * N_EPOCH
+                cp = (t["tau0"] + start * step_c) % CODE_LEN
+                rem = -cp
+                if rem < -CODE_LEN / 2:
+                    rem += CODE_LEN
+                carr = (t["phi"] + 2 * np.pi * t["doppler"] * start / FS) % (2 * np.pi)
+                recs.append((start, np.float32(carr), np.float32(2 * np.pi * t["doppler"] / FS), np.float32(rem), np.float32(step_c)))
+            v, n_done, dt = cpu_baseline(codes[0], shifts, sig0, recs, args.cpu_seconds)
+            cpu = {"value": v, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": "%d channel-epochs of the same workload (GPS L1 C/A, N=25000, 3 taps) in %.1f s, oracle "
+                          "(volk_gnsssdr generic restatement, gcc -O3 -march=native), 1 thread" % (n_done, dt)}
+
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Msamples/s tracked (N-channel multicorrelator, whole job)",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GPS L1 C/A, 32 channels/GPU, 25 Msps, 3-tap E/P/L multicorrelator, "
+                                   "%d code periods (25000 samples) per channel per step, distinct IQ buffer per channel" % E,
+                "channels_per_gpu": N_CHANNELS, "epochs_per_step": E, "samples_per_epoch": N_EPOCH,
+                "parallelism": "channels sharded over %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "kernel": "trk_multicorrelator_kernel<3,false,false>", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu,
+        }
+        result.update(extra)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

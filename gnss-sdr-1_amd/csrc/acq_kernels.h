@@ -1,0 +1,86 @@
+// acq_kernels.h -- device-side pieces of the PCPS acquisition engine.
+#ifndef ACQ_KERNELS_H
+#define ACQ_KERNELS_H
+#include "gnsscorr.h"
+#include <hip/hip_runtime.h>
+
+#define ACQ_MAX_FACTORS 12
+#define ACQ_MAX_N1 32
+
+// N-point FFT as N = N1 x N2: N2-point row FFTs in LDS, N1-point column DFTs in registers
+struct AcqFftPlan
+{
+    int N, N1, N2;
+    int n_fac;
+    int fac[ACQ_MAX_FACTORS];  // radices of the N2-point row FFT, product = N2
+    float2 w1[ACQ_MAX_N1];     // exp(-2*pi*j*k/N1), k < N1
+};
+
+// which array slice a cell reads: index = (cell / div) % mod
+struct AcqCellMap
+{
+    int div, mod;
+};
+
+enum
+{
+    ACQ_EPI_COMPLEX = 0,  // store the transform (natural order)
+    ACQ_EPI_COMPLEX_CONJ_PERM = 1,  // store conj(transform) in row-permuted order (code FFT)
+    ACQ_EPI_PERM = 2,     // store the transform in row-permuted order (signal FFT)
+    ACQ_EPI_MAG = 3       // |.|^2 into the search grid (+ per-block row maxima)
+};
+
+struct AcqMagArgs
+{
+    float* grid;          // [cell][fft_size]
+    float* tmp;           // per-satellite d_tmp_buffer image [sat][fft_size] (may be null)
+    float* blk_max_val;   // [cell][n_blocks]
+    unsigned* blk_max_idx;
+    int accumulate;       // 0: first dwell (store), 1: add to the grid
+    int offset;           // first kept output sample (bit_transition: fft_size/2)
+    int eff;              // kept samples per row
+    int n_bins;           // cells per satellite
+    int tmp_bin;          // bin whose single-dwell magnitudes are mirrored into tmp (accumulate only)
+};
+
+bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes);
+size_t acq_rows_lds_bytes(const AcqFftPlan& plan);
+
+// out[a*N2 + b] = in[a + N1*b] (* mul[a + N1*b]); in is zero beyond n_valid
+hipError_t acq_launch_permute(hipStream_t st, const float2* in, const float2* mul, float2* out,
+    const AcqFftPlan& plan, int n_valid, int n_arrays, size_t in_stride, size_t mul_stride, size_t out_stride);
+
+// rows pass: Q[cell][k1][n2] = twiddle * FFT_N2(A[mapA(cell)][k1][.] * B[mapB(cell)][k1][.])
+hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan, int n_cells,
+    const float2* A, AcqCellMap mapA, const float2* B, AcqCellMap mapB,
+    float2* Q, const float2* wN2, const float2* wN);
+
+// columns pass + epilogue
+hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const AcqFftPlan& plan, int n_cells,
+    const float2* Q, float2* out, const AcqMagArgs* mag);
+
+int acq_cols_blocks(const AcqFftPlan& plan);
+
+// phase[bin][n] = float32 running sum of phase_inc[bin] (volk_gnsssdr_s32f_sincos_32fc); out = (cos, sin)
+hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float2* out, int n_bins, int N);
+
+hipError_t acq_launch_input_power(hipStream_t st, const float2* x, int n_valid, int N, float* out_power, float* tmp_all,
+    int n_sats, size_t tmp_stride);
+
+struct AcqFinalArgs
+{
+    const float* grid;
+    float* tmp;  // [sat][fft_size]
+    const float* blk_max_val;
+    const unsigned* blk_max_idx;
+    const float* input_power;
+    gc_acq_result* results;
+    int n_bins, n_blocks, fft_size;
+    int doppler_max, doppler_step;
+    int use_cfar;
+    int samples_per_chip;
+    float samples_per_code;
+};
+hipError_t acq_launch_final(hipStream_t st, const AcqFinalArgs& a, int n_sats);
+
+#endif

@@ -1,0 +1,797 @@
+// acq_kernels.hip -- PCPS acquisition kernels for gfx950 (MI355X).
+//
+// Reference path: pcps_acquisition::acquisition_core
+// (src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.cc:668-770):
+//   per Doppler bin  x*wipeoff -> FFT -> * conj(FFT(code)) -> IFFT -> |.|^2 -> grid (+=)
+// followed by max_to_input_power_statistic (:565-596) or
+// first_vs_second_peak_statistic (:599-665).
+//
+// FFT sizes are one code period of samples (4000, 25000, 100000 ...), not powers
+// of two.  An N-point transform is split N = N1 x N2 (Cooley-Tukey "four step"):
+//   rows    : N1 independent N2-point FFTs, each in LDS (Stockham autosort,
+//             radix 8/5/4/3/2 + generic prime), one 256-thread workgroup per row
+//   twiddle : w_N^(k1*n2), applied when the row leaves LDS
+//   columns : N2 independent N1-point DFTs, each in the registers of one thread
+// Rows consume the "row-permuted" layout P[a][b] = v[a + N1*b] and columns
+// produce natural order, so every global access is a coalesced row.  The
+// element-wise product with conj(FFT(code)) is fused into the row load and
+// |.|^2 + non-coherent accumulation + row maximum into the column epilogue.
+#include "acq_kernels.h"
+#include <cmath>
+#include <cstring>
+
+#define ACQ_THREADS 256
+
+static __device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+static __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)  // a * conj(b)
+{
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+static __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+static __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -j (forward) or +j (inverse)
+template <bool INV>
+static __device__ __forceinline__ float2 mul_mj(float2 a)
+{
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+// ---- small DFTs on registers (forward kernel exp(-j...), INV -> exp(+j...)) ----
+template <bool INV>
+static __device__ __forceinline__ void dft2(float2* a)
+{
+    float2 t = a[0];
+    a[0] = cadd(t, a[1]);
+    a[1] = csub(t, a[1]);
+}
+template <bool INV>
+static __device__ __forceinline__ void dft3(float2* a)
+{
+    const float s60 = 0.86602540378443864676f;
+    float2 t = cadd(a[1], a[2]);
+    float2 d = csub(a[1], a[2]);
+    float2 m = make_float2(fmaf(-0.5f, t.x, a[0].x), fmaf(-0.5f, t.y, a[0].y));
+    float2 s = mul_mj<INV>(make_float2(s60 * d.x, s60 * d.y));
+    a[0] = cadd(a[0], t);
+    a[1] = cadd(m, s);
+    a[2] = csub(m, s);
+}
+template <bool INV>
+static __device__ __forceinline__ void dft4(float2* a)
+{
+    float2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
+    float2 t2 = cadd(a[1], a[3]), t3 = mul_mj<INV>(csub(a[1], a[3]));
+    a[0] = cadd(t0, t2);
+    a[2] = csub(t0, t2);
+    a[1] = cadd(t1, t3);
+    a[3] = csub(t1, t3);
+}
+template <bool INV>
+static __device__ __forceinline__ void dft5(float2* a)
+{
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    float2 t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
+    float2 t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+    float2 m1 = make_float2(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
+    float2 m2 = make_float2(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
+    float2 u1 = mul_mj<INV>(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+    float2 u2 = mul_mj<INV>(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+    a[0] = make_float2(a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y);
+    a[1] = cadd(m1, u1);
+    a[4] = csub(m1, u1);
+    a[2] = cadd(m2, u2);
+    a[3] = csub(m2, u2);
+}
+template <bool INV>
+static __device__ __forceinline__ void dft8(float2* a)
+{
+    const float h = 0.70710678118654752440f;
+    float2 e[4] = {a[0], a[2], a[4], a[6]};
+    float2 o[4] = {a[1], a[3], a[5], a[7]};
+    dft4<INV>(e);
+    dft4<INV>(o);
+    // w8^k * o[k]
+    float2 o1 = INV ? make_float2(h * (o[1].x - o[1].y), h * (o[1].x + o[1].y))
+                    : make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+    float2 o2 = mul_mj<INV>(o[2]);
+    float2 o3 = INV ? make_float2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y))
+                    : make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+    a[0] = cadd(e[0], o[0]);
+    a[4] = csub(e[0], o[0]);
+    a[1] = cadd(e[1], o1);
+    a[5] = csub(e[1], o1);
+    a[2] = cadd(e[2], o2);
+    a[6] = csub(e[2], o2);
+    a[3] = cadd(e[3], o3);
+    a[7] = csub(e[3], o3);
+}
+
+template <int R, bool INV>
+static __device__ __forceinline__ void dftR(float2* a)
+{
+    if (R == 2) dft2<INV>(a);
+    if (R == 3) dft3<INV>(a);
+    if (R == 4) dft4<INV>(a);
+    if (R == 5) dft5<INV>(a);
+    if (R == 8) dft8<INV>(a);
+}
+
+// ---- one Stockham stage of the LDS row FFT ----
+// current length n = R*m, stride s (product of the radices already done), N2 = n*s.
+//   y[r + s*(R*q + k)] = w_n^(q*k) * sum_j x[r + s*(q + m*j)] * w_R^(j*k)
+template <int R, bool INV>
+static __device__ __forceinline__ void lds_stage(const float2* __restrict__ x, float2* __restrict__ y,
+    const float2* __restrict__ tw, int N2, int m, int s)
+{
+    const int nb = N2 / R;
+    for (int u = threadIdx.x; u < nb; u += ACQ_THREADS)
+        {
+            const int r = u % s, q = u / s;
+            float2 a[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) a[j] = x[r + s * (q + m * j)];
+            dftR<R, INV>(a);
+            const int base = r + s * R * q;
+            y[base] = a[0];
+#pragma unroll
+            for (int k = 1; k < R; k++)
+                {
+                    float2 w = tw[q * k * s];  // w_n^(q*k) = w_N2^(q*k*s)
+                    y[base + s * k] = INV ? cmul_conj(a[k], w) : cmul(a[k], w);
+                }
+        }
+}
+
+// generic (prime) radix: O(R^2) butterfly with table twiddles
+template <bool INV>
+static __device__ void lds_stage_generic(const float2* __restrict__ x, float2* __restrict__ y,
+    const float2* __restrict__ tw, int N2, int R, int m, int s)
+{
+    const int nb = N2 / R;
+    const int wR = N2 / R;  // w_R^e = w_N2^(e*N2/R)
+    for (int u = threadIdx.x; u < nb; u += ACQ_THREADS)
+        {
+            const int r = u % s, q = u / s;
+            for (int k = 0; k < R; k++)
+                {
+                    float2 acc = make_float2(0.f, 0.f);
+                    for (int j = 0; j < R; j++)
+                        {
+                            float2 v = x[r + s * (q + m * j)];
+                            float2 w = tw[((j * k) % R) * wR];
+                            float2 p = INV ? cmul_conj(v, w) : cmul(v, w);
+                            acc = cadd(acc, p);
+                        }
+                    float2 w = tw[q * k * s];
+                    y[r + s * (R * q + k)] = INV ? cmul_conj(acc, w) : cmul(acc, w);
+                }
+        }
+}
+
+// ---- rows pass ----
+template <bool INV>
+__global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
+    const float2* __restrict__ A, AcqCellMap mapA, const float2* __restrict__ B, AcqCellMap mapB,
+    float2* __restrict__ Q, const float2* __restrict__ wN2, const float2* __restrict__ wN)
+{
+    extern __shared__ float2 sm[];
+    const int N2 = plan.N2, N = plan.N;
+    float2* buf0 = sm;
+    float2* buf1 = sm + N2;
+    float2* tw = sm + 2 * N2;
+    const int k1 = blockIdx.x;
+    const int cell = blockIdx.y;
+    const size_t row = (size_t)k1 * N2;
+    const float2* a = A + (size_t)((cell / mapA.div) % mapA.mod) * N + row;
+    for (int i = threadIdx.x; i < N2; i += ACQ_THREADS) tw[i] = wN2[i];
+    if (B)
+        {
+            const float2* bb = B + (size_t)((cell / mapB.div) % mapB.mod) * N + row;
+            for (int i = threadIdx.x; i < N2; i += ACQ_THREADS) buf0[i] = cmul(a[i], bb[i]);
+        }
+    else
+        {
+            for (int i = threadIdx.x; i < N2; i += ACQ_THREADS) buf0[i] = a[i];
+        }
+    __syncthreads();
+    float2* src = buf0;
+    float2* dst = buf1;
+    int n = N2, s = 1;
+    for (int f = 0; f < plan.n_fac; f++)
+        {
+            const int R = plan.fac[f];
+            const int m = n / R;
+            switch (R)
+                {
+                case 2: lds_stage<2, INV>(src, dst, tw, N2, m, s); break;
+                case 3: lds_stage<3, INV>(src, dst, tw, N2, m, s); break;
+                case 4: lds_stage<4, INV>(src, dst, tw, N2, m, s); break;
+                case 5: lds_stage<5, INV>(src, dst, tw, N2, m, s); break;
+                case 8: lds_stage<8, INV>(src, dst, tw, N2, m, s); break;
+                default: lds_stage_generic<INV>(src, dst, tw, N2, R, m, s); break;
+                }
+            __syncthreads();
+            float2* t = src;
+            src = dst;
+            dst = t;
+            n = m;
+            s *= R;
+        }
+    // leave LDS through the inter-pass twiddle w_N^(k1*n2)
+    float2* q = Q + (size_t)cell * N + row;
+    for (int i = threadIdx.x; i < N2; i += ACQ_THREADS)
+        {
+            float2 v = src[i];
+            if (k1 > 0)
+                {
+                    float2 w = wN[(size_t)k1 * i];
+                    v = INV ? cmul_conj(v, w) : cmul(v, w);
+                }
+            q[i] = v;
+        }
+}
+
+// ---- register-resident N1-point DFT (Stockham, fully unrolled) ----
+template <int N>
+struct PickRadix
+{
+    static constexpr int value = (N % 5 == 0) ? 5 : (N % 4 == 0) ? 4 : (N % 3 == 0) ? 3 : (N % 2 == 0) ? 2 : N;
+};
+
+template <int NCUR, int S, int NTOT, bool INV>
+struct RegFft
+{
+    // x: input, y: scratch; returns pointer parity through the recursion: result in `x` if the
+    // number of stages is even, else in `y` (resolved at compile time by result_in_x)
+    static constexpr int R = PickRadix<NCUR>::value;
+    static constexpr int M = NCUR / R;
+    static __device__ __forceinline__ void run(float2* x, float2* y, const float2* w)
+    {
+#pragma unroll
+        for (int q = 0; q < M; q++)
+            {
+#pragma unroll
+                for (int r = 0; r < S; r++)
+                    {
+                        float2 a[R];
+#pragma unroll
+                        for (int j = 0; j < R; j++) a[j] = x[r + S * (q + M * j)];
+                        dftR<R, INV>(a);
+#pragma unroll
+                        for (int k = 0; k < R; k++)
+                            {
+                                float2 v = a[k];
+                                if (q * k != 0)
+                                    {
+                                        float2 tw = w[(q * k * S) % NTOT];
+                                        v = INV ? cmul_conj(v, tw) : cmul(v, tw);
+                                    }
+                                y[r + S * (R * q + k)] = v;
+                            }
+                    }
+            }
+        RegFft<M, S * R, NTOT, INV>::run(y, x, w);
+    }
+    static constexpr bool result_in_first = !RegFft<M, S * R, NTOT, INV>::result_in_first;
+};
+template <int S, int NTOT, bool INV>
+struct RegFft<1, S, NTOT, INV>
+{
+    static __device__ __forceinline__ void run(float2*, float2*, const float2*) {}
+    static constexpr bool result_in_first = true;
+};
+
+struct MaxPair
+{
+    float v;
+    unsigned i;
+};
+// reference semantics of volk_gnsssdr_32f_index_max_32u: the first maximum wins
+static __device__ __forceinline__ MaxPair max_pair(MaxPair a, MaxPair b)
+{
+    bool take_b = (b.v > a.v) || (b.v == a.v && b.i < a.i);
+    return take_b ? b : a;
+}
+
+template <int N1, bool INV, int EPI>
+__global__ __launch_bounds__(ACQ_THREADS) void acq_cols_kernel(AcqFftPlan plan, const float2* __restrict__ Q,
+    float2* __restrict__ out, AcqMagArgs mag)
+{
+    const int N2 = plan.N2, N = plan.N;
+    const int n2 = blockIdx.x * ACQ_THREADS + threadIdx.x;
+    const int cell = blockIdx.y;
+    const bool active = n2 < N2;
+    float2 v0[N1], v1[N1];
+    const float2* q = Q + (size_t)cell * N;
+#pragma unroll
+    for (int k = 0; k < N1; k++) v0[k] = active ? q[(size_t)k * N2 + n2] : make_float2(0.f, 0.f);
+    RegFft<N1, 1, N1, INV>::run(v0, v1, plan.w1);
+    float2* res = RegFft<N1, 1, N1, INV>::result_in_first ? v0 : v1;
+
+    if (EPI == ACQ_EPI_COMPLEX)
+        {
+            if (active)
+                {
+                    float2* o = out + (size_t)cell * N;
+#pragma unroll
+                    for (int k = 0; k < N1; k++) o[(size_t)k * N2 + n2] = res[k];
+                }
+        }
+    else if (EPI == ACQ_EPI_PERM || EPI == ACQ_EPI_COMPLEX_CONJ_PERM)
+        {
+            // natural index m = n2 + N2*k  ->  row-permuted position (m % N1)*N2 + m / N1
+            if (active)
+                {
+                    float2* o = out + (size_t)cell * N;
+#pragma unroll
+                    for (int k = 0; k < N1; k++)
+                        {
+                            int m = n2 + N2 * k;
+                            float2 v = res[k];
+                            if (EPI == ACQ_EPI_COMPLEX_CONJ_PERM) v.y = -v.y;
+                            o[(size_t)(m % N1) * N2 + m / N1] = v;
+                        }
+                }
+        }
+    else
+        {
+            // |.|^2, non-coherent accumulation, per-block maximum of the grid row
+            float* g = mag.grid + (size_t)cell * N;
+            const int sat = cell / mag.n_bins, bin = cell % mag.n_bins;
+            float* tmp = (mag.tmp && mag.accumulate && bin == mag.tmp_bin) ? mag.tmp + (size_t)sat * N : nullptr;
+            MaxPair best = {-1.0f, 0xffffffffu};
+            if (active)
+                {
+#pragma unroll
+                    for (int k = 0; k < N1; k++)
+                        {
+                            const int m = n2 + N2 * k;   // natural output index
+                            const int idx = m - mag.offset;  // grid column
+                            if (idx >= 0 && idx < mag.eff)
+                                {
+                                    float p = res[k].x * res[k].x + res[k].y * res[k].y;
+                                    float val = p;
+                                    if (mag.accumulate)
+                                        {
+                                            if (tmp) tmp[idx] = p;
+                                            val = g[idx] + p;
+                                        }
+                                    g[idx] = val;
+                                    MaxPair c = {val, (unsigned)idx};
+                                    best = max_pair(best, c);
+                                }
+                        }
+                }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                {
+                    MaxPair o;
+                    o.v = __shfl_down(best.v, off, 64);
+                    o.i = __shfl_down(best.i, off, 64);
+                    best = max_pair(best, o);
+                }
+            __shared__ float sv[ACQ_THREADS / 64];
+            __shared__ unsigned si[ACQ_THREADS / 64];
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            if (lane == 0)
+                {
+                    sv[wave] = best.v;
+                    si[wave] = best.i;
+                }
+            __syncthreads();
+            if (threadIdx.x == 0)
+                {
+                    MaxPair b = {sv[0], si[0]};
+                    for (int w = 1; w < ACQ_THREADS / 64; w++)
+                        {
+                            MaxPair c = {sv[w], si[w]};
+                            b = max_pair(b, c);
+                        }
+                    mag.blk_max_val[(size_t)cell * gridDim.x + blockIdx.x] = b.v;
+                    mag.blk_max_idx[(size_t)cell * gridDim.x + blockIdx.x] = b.i;
+                }
+        }
+}
+
+// ---- permutation (gather): out[a*N2 + b] = in[a + N1*b] (* mul[...]) ----
+__global__ void acq_permute_kernel(const float2* __restrict__ in, const float2* __restrict__ mul,
+    float2* __restrict__ out, int N, int N1, int N2, int n_valid, size_t in_stride, size_t mul_stride, size_t out_stride)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int arr = blockIdx.y;
+    if (o >= N) return;
+    const int a = o / N2, b = o % N2;
+    const int src = a + N1 * b;
+    float2 v = make_float2(0.f, 0.f);
+    if (src < n_valid)
+        {
+            v = in[(size_t)arr * in_stride + src];
+            if (mul)
+                {
+                    // volk_32fc_x2_multiply_32fc(in, wipeoff) (pcps_acquisition.cc:717)
+                    float2 w = mul[(size_t)arr * mul_stride + src];
+                    v = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+                }
+        }
+    out[(size_t)arr * out_stride + o] = v;
+}
+
+// ---- Doppler wipe-off table (pcps_acquisition::update_local_carrier, :296-310) ----
+// volk_gnsssdr_s32f_sincos_32fc_generic: _phase += phase_inc in float32, out = (cosf, sinf)
+__global__ void acq_wipeoff_phase_kernel(const float* __restrict__ phase_inc, float* __restrict__ phase, int n_bins, int N)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= n_bins) return;
+    const float inc = phase_inc[bin];
+    float p = 0.0f;
+    float* row = phase + (size_t)bin * N;
+    for (int i = 0; i < N; i++)
+        {
+            row[i] = p;
+            p = p + inc;  // sequential float32 running sum, exactly as the reference
+        }
+}
+__global__ void acq_wipeoff_sincos_kernel(const float* __restrict__ phase, float2* __restrict__ out, size_t total)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s, c;
+    sincosf(phase[i], &s, &c);
+    out[i] = make_float2(c, s);
+}
+
+// ---- input power (pcps_acquisition.cc:703-709) ----
+__global__ __launch_bounds__(1024) void acq_input_power_kernel(const float2* __restrict__ x, int n_valid, int N,
+    float* __restrict__ out_power, float* __restrict__ tmp_all, int n_sats, size_t tmp_stride)
+{
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N; i += 1024)
+        {
+            float p = 0.f;
+            if (i < n_valid)
+                {
+                    float2 v = x[i];
+                    p = v.x * v.x + v.y * v.y;
+                }
+            acc += p;
+            // d_tmp_buffer holds |x|^2 after this step (:706); mirrored for every satellite
+            if (tmp_all)
+                for (int s = 0; s < n_sats; s++) tmp_all[(size_t)s * tmp_stride + i] = p;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        {
+            float t = 0.f;
+            for (int w = 0; w < 16; w++) t += red[w];
+            *out_power = t / (float)N;
+        }
+}
+
+// ---- final statistics, one workgroup per satellite ----
+__global__ __launch_bounds__(ACQ_THREADS) void acq_final_kernel(AcqFinalArgs a)
+{
+    const int sat = blockIdx.x;
+    const int N = a.fft_size;
+    __shared__ float s_peak;
+    __shared__ unsigned s_row, s_time;
+    __shared__ float sv[ACQ_THREADS / 64];
+    __shared__ unsigned si[ACQ_THREADS / 64];
+    if (threadIdx.x == 0)
+        {
+            // rows in increasing Doppler, strict '>' (pcps_acquisition.cc:575-585 / :611-621)
+            float peak = 0.0f;
+            unsigned row = 0, tim = 0;
+            for (int d = 0; d < a.n_bins; d++)
+                {
+                    const size_t cell = (size_t)sat * a.n_bins + d;
+                    MaxPair b = {a.blk_max_val[cell * a.n_blocks], a.blk_max_idx[cell * a.n_blocks]};
+                    for (int k = 1; k < a.n_blocks; k++)
+                        {
+                            MaxPair c = {a.blk_max_val[cell * a.n_blocks + k], a.blk_max_idx[cell * a.n_blocks + k]};
+                            b = max_pair(b, c);
+                        }
+                    if (b.i == 0xffffffffu)
+                        {
+                            b.i = 0;
+                            b.v = a.grid[cell * N];
+                        }
+                    if (b.v > peak)
+                        {
+                            peak = b.v;
+                            row = (unsigned)d;
+                            tim = b.i;
+                        }
+                }
+            s_peak = peak;
+            s_row = row;
+            s_time = tim;
+        }
+    __syncthreads();
+    const float peak = s_peak;
+    const unsigned row = s_row, tim = s_time;
+    gc_acq_result r;
+    r.indext = tim;
+    r.doppler_index = row;
+    r.doppler_hz = -a.doppler_max + a.doppler_step * (int)row;
+    r.mag = peak;
+    r.input_power = a.input_power ? *a.input_power : 0.0f;
+    r.second_peak = 0.0f;
+    r.second_peak_full_row = 0.0f;
+    r.test_statistics = 0.0f;
+    if (a.use_cfar)
+        {
+            // max_to_input_power_statistic (:571,594-595)
+            float nf = (float)N * (float)N;
+            float magt = peak / (nf * nf);
+            r.test_statistics = magt / r.input_power;
+        }
+    else
+        {
+            // first_vs_second_peak_statistic (:627-664)
+            int e1 = (int)tim - a.samples_per_chip;
+            int e2 = (int)tim + a.samples_per_chip;
+            if (e1 < 0)
+                e1 = N + e1;
+            else if (e2 >= N)
+                e2 = e2 - N;
+            const float* grow = a.grid + ((size_t)sat * a.n_bins + row) * N;
+            float* tmp = a.tmp + (size_t)sat * N;
+            // memcpy(d_tmp_buffer, row, d_fft_size) copies d_fft_size BYTES = N/4 floats (:647)
+            const int n_copied = N / 4;
+            // excluded indices: e1, e1+1, ... (circular) up to but excluding e2; the loop is a
+            // do-while, so e1 is always cleared
+            MaxPair best_bug = {-1.0f, 0xffffffffu}, best_full = {-1.0f, 0xffffffffu};
+            for (int i = threadIdx.x; i < N; i += ACQ_THREADS)
+                {
+                    int d = i - e1;
+                    if (d < 0) d += N;
+                    int len = e2 - e1;
+                    if (len <= 0) len += N;
+                    const bool excluded = d < len;
+                    float vb = (i < n_copied) ? grow[i] : tmp[i];
+                    float vf = grow[i];
+                    if (excluded)
+                        {
+                            vb = 0.0f;
+                            vf = 0.0f;
+                        }
+                    tmp[i] = vb;  // the scratch keeps these contents for the next call, like d_tmp_buffer
+                    MaxPair cb = {vb, (unsigned)i}, cf = {vf, (unsigned)i};
+                    best_bug = max_pair(best_bug, cb);
+                    best_full = max_pair(best_full, cf);
+                }
+            for (int pass = 0; pass < 2; pass++)
+                {
+                    MaxPair b = pass ? best_full : best_bug;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1)
+                        {
+                            MaxPair o;
+                            o.v = __shfl_down(b.v, off, 64);
+                            o.i = __shfl_down(b.i, off, 64);
+                            b = max_pair(b, o);
+                        }
+                    __syncthreads();
+                    if ((threadIdx.x & 63) == 0)
+                        {
+                            sv[threadIdx.x >> 6] = b.v;
+                            si[threadIdx.x >> 6] = b.i;
+                        }
+                    __syncthreads();
+                    MaxPair t = {sv[0], si[0]};
+                    for (int w = 1; w < ACQ_THREADS / 64; w++)
+                        {
+                            MaxPair c = {sv[w], si[w]};
+                            t = max_pair(t, c);
+                        }
+                    if (pass)
+                        r.second_peak_full_row = t.v;
+                    else
+                        r.second_peak = t.v;
+                }
+            r.test_statistics = peak / r.second_peak;
+        }
+    // :764-768
+    r.acq_delay_samples = (double)fmodf((float)tim, a.samples_per_code);
+    r.acq_doppler_hz = (double)r.doppler_hz;
+    if (threadIdx.x == 0) a.results[sat] = r;
+}
+
+// -----------------------------------------------------------------------------
+// host side: plan + launchers
+// -----------------------------------------------------------------------------
+static bool factor_rows(int N2, int* fac, int* n_fac)
+{
+    int n = N2, k = 0;
+    const int pref[] = {8, 5, 4, 3, 2};
+    while (n > 1)
+        {
+            int r = 0;
+            for (int p : pref)
+                if (n % p == 0)
+                    {
+                        r = p;
+                        break;
+                    }
+            if (!r)
+                {
+                    for (int p = 7; p <= 61; p += 2)
+                        if (n % p == 0)
+                            {
+                                r = p;
+                                break;
+                            }
+                }
+            if (!r || k >= ACQ_MAX_FACTORS) return false;
+            fac[k++] = r;
+            n /= r;
+        }
+    *n_fac = k;
+    return true;
+}
+
+size_t acq_rows_lds_bytes(const AcqFftPlan& plan) { return (size_t)3 * plan.N2 * sizeof(float2); }
+
+bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes)
+{
+    std::memset(plan, 0, sizeof *plan);
+    if (N < 1) return false;
+    // N1 candidates (register DFT sizes that are instantiated); prefer rows of ~1000-2000 points:
+    // long enough to occupy a 256-thread workgroup, short enough for several workgroups per CU
+    const int cands[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25};
+    int best = 0;
+    long best_cost = -1;
+    for (int n1 : cands)
+        {
+            if (N % n1) continue;
+            int n2 = N / n1;
+            if ((size_t)3 * n2 * sizeof(float2) > lds_limit_bytes) continue;
+            int fac[ACQ_MAX_FACTORS], nf;
+            if (!factor_rows(n2, fac, &nf)) continue;
+            long cost = labs((long)n2 - 1024);
+            if (best_cost < 0 || cost < best_cost)
+                {
+                    best_cost = cost;
+                    best = n1;
+                }
+        }
+    if (!best) return false;
+    plan->N = N;
+    plan->N1 = best;
+    plan->N2 = N / best;
+    factor_rows(plan->N2, plan->fac, &plan->n_fac);
+    for (int k = 0; k < best; k++)
+        {
+            double a = -2.0 * M_PI * (double)k / (double)best;
+            plan->w1[k] = make_float2((float)cos(a), (float)sin(a));
+        }
+    return true;
+}
+
+hipError_t acq_launch_permute(hipStream_t st, const float2* in, const float2* mul, float2* out,
+    const AcqFftPlan& plan, int n_valid, int n_arrays, size_t in_stride, size_t mul_stride, size_t out_stride)
+{
+    dim3 grid((plan.N + 255) / 256, n_arrays);
+    hipLaunchKernelGGL(acq_permute_kernel, grid, dim3(256), 0, st, in, mul, out, plan.N, plan.N1, plan.N2, n_valid,
+        in_stride, mul_stride, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan, int n_cells,
+    const float2* A, AcqCellMap mapA, const float2* B, AcqCellMap mapB,
+    float2* Q, const float2* wN2, const float2* wN)
+{
+    dim3 grid(plan.N1, n_cells);
+    size_t lds = acq_rows_lds_bytes(plan);
+    if (lds > 64 * 1024)
+        {
+            // rows longer than 2730 points need more than the default 64 KB of dynamic LDS
+            hipError_t ea = inverse ? hipFuncSetAttribute(reinterpret_cast<const void*>(&acq_rows_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                    : hipFuncSetAttribute(reinterpret_cast<const void*>(&acq_rows_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
+        }
+    if (inverse)
+        hipLaunchKernelGGL(acq_rows_kernel<true>, grid, dim3(ACQ_THREADS), lds, st, plan, A, mapA, B, mapB, Q, wN2, wN);
+    else
+        hipLaunchKernelGGL(acq_rows_kernel<false>, grid, dim3(ACQ_THREADS), lds, st, plan, A, mapA, B, mapB, Q, wN2, wN);
+    return hipGetLastError();
+}
+
+int acq_cols_blocks(const AcqFftPlan& plan) { return (plan.N2 + ACQ_THREADS - 1) / ACQ_THREADS; }
+
+template <int N1>
+static hipError_t launch_cols_n1(hipStream_t st, bool inverse, int epilogue, const AcqFftPlan& plan, dim3 grid,
+    const float2* Q, float2* out, const AcqMagArgs& mag)
+{
+#define LAUNCH(INV, EPI) \
+    hipLaunchKernelGGL((acq_cols_kernel<N1, INV, EPI>), grid, dim3(ACQ_THREADS), 0, st, plan, Q, out, mag)
+    if (inverse)
+        {
+            switch (epilogue)
+                {
+                case ACQ_EPI_COMPLEX: LAUNCH(true, ACQ_EPI_COMPLEX); break;
+                case ACQ_EPI_MAG: LAUNCH(true, ACQ_EPI_MAG); break;
+                default: return hipErrorInvalidValue;
+                }
+        }
+    else
+        {
+            switch (epilogue)
+                {
+                case ACQ_EPI_COMPLEX: LAUNCH(false, ACQ_EPI_COMPLEX); break;
+                case ACQ_EPI_PERM: LAUNCH(false, ACQ_EPI_PERM); break;
+                case ACQ_EPI_COMPLEX_CONJ_PERM: LAUNCH(false, ACQ_EPI_COMPLEX_CONJ_PERM); break;
+                default: return hipErrorInvalidValue;
+                }
+        }
+#undef LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const AcqFftPlan& plan, int n_cells,
+    const float2* Q, float2* out, const AcqMagArgs* mag)
+{
+    dim3 grid(acq_cols_blocks(plan), n_cells);
+    AcqMagArgs m;
+    std::memset(&m, 0, sizeof m);
+    if (mag) m = *mag;
+    switch (plan.N1)
+        {
+#define CASE(K) \
+    case K: return launch_cols_n1<K>(st, inverse, epilogue, plan, grid, Q, out, m);
+            CASE(1)
+            CASE(2)
+            CASE(3)
+            CASE(4)
+            CASE(5)
+            CASE(6)
+            CASE(8)
+            CASE(9)
+            CASE(10)
+            CASE(12)
+            CASE(15)
+            CASE(16)
+            CASE(20)
+            CASE(25)
+#undef CASE
+        default:
+            return hipErrorInvalidValue;
+        }
+}
+
+hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float2* out, int n_bins, int N)
+{
+    // the float32 phase table reuses the output buffer's second half as scratch? no: separate pass
+    float* phase = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&phase), sizeof(float) * (size_t)n_bins * N, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(acq_wipeoff_phase_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, st, phase_inc, phase, n_bins, N);
+    size_t total = (size_t)n_bins * N;
+    hipLaunchKernelGGL(acq_wipeoff_sincos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, phase, out, total);
+    e = hipGetLastError();
+    hipError_t e2 = hipFreeAsync(phase, st);
+    return e != hipSuccess ? e : e2;
+}
+
+hipError_t acq_launch_input_power(hipStream_t st, const float2* x, int n_valid, int N, float* out_power, float* tmp_all,
+    int n_sats, size_t tmp_stride)
+{
+    hipLaunchKernelGGL(acq_input_power_kernel, dim3(1), dim3(1024), 0, st, x, n_valid, N, out_power, tmp_all, n_sats, tmp_stride);
+    return hipGetLastError();
+}
+
+hipError_t acq_launch_final(hipStream_t st, const AcqFinalArgs& a, int n_sats)
+{
+    hipLaunchKernelGGL(acq_final_kernel, dim3(n_sats), dim3(ACQ_THREADS), 0, st, a);
+    return hipGetLastError();
+}

@@ -1,0 +1,359 @@
+// gc_acquisition.hip -- host side of the PCPS acquisition path of libgnsscorr.so.
+// Mirrors pcps_acquisition (src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.cc):
+// constructor sizes (:63-190), set_local_code (:239-274), init (:313-368),
+// acquisition_core (:668-770) -- batched over n_sats satellites that search the
+// same input block.
+#include "acq_kernels.h"
+#include "gc_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct gc_acq
+{
+    gc_ctx* ctx = nullptr;
+    gc_acq_conf conf{};
+    int n_sats = 0;
+    uint32_t fft_size = 0, consumed = 0, eff = 0, n_bins = 0;
+    bool use_cfar = false;
+    uint32_t max_dwells = 1;
+    uint32_t dwell_counter = 0;
+    AcqFftPlan plan{};
+    int n_blocks = 0;
+    int sats_per_batch = 1;
+    float2* d_wN = nullptr;
+    float2* d_wN2 = nullptr;
+    float2* d_wipe = nullptr;
+    float2* d_codes = nullptr;
+    float2* d_xw = nullptr;
+    float2* d_X = nullptr;
+    float2* d_Q = nullptr;
+    float* d_grid = nullptr;
+    float* d_tmp = nullptr;
+    float* d_blkv = nullptr;
+    unsigned* d_blki = nullptr;
+    float* d_power = nullptr;
+    float2* d_in = nullptr;
+    gc_acq_result* d_results = nullptr;
+    gc_acq_result* h_results = nullptr;  // pinned
+    std::vector<char> code_set;
+};
+
+static void acq_release(gc_acq* a)
+{
+    (void)hipFree(a->d_wN);
+    (void)hipFree(a->d_wN2);
+    (void)hipFree(a->d_wipe);
+    (void)hipFree(a->d_codes);
+    (void)hipFree(a->d_xw);
+    (void)hipFree(a->d_X);
+    (void)hipFree(a->d_Q);
+    (void)hipFree(a->d_grid);
+    (void)hipFree(a->d_tmp);
+    (void)hipFree(a->d_blkv);
+    (void)hipFree(a->d_blki);
+    (void)hipFree(a->d_power);
+    (void)hipFree(a->d_in);
+    (void)hipFree(a->d_results);
+    if (a->h_results) (void)hipHostFree(a->h_results);
+}
+
+#define ACQ_TRY(call)                                                                                  \
+    do                                                                                                 \
+        {                                                                                              \
+            hipError_t e_ = (call);                                                                    \
+            if (e_ != hipSuccess)                                                                      \
+                {                                                                                      \
+                    acq_release(a);                                                                    \
+                    delete a;                                                                          \
+                    return gc_fail(GC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));         \
+                }                                                                                      \
+        }                                                                                              \
+    while (0)
+
+extern "C" {
+
+gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq** out)
+{
+    GC_REQUIRE(ctx && conf && out, "gc_acq_create: NULL argument");
+    *out = nullptr;
+    GC_REQUIRE(n_sats > 0, "gc_acq_create: n_sats must be > 0");
+    GC_REQUIRE(conf->sampled_ms > 0 && conf->ms_per_code > 0 && conf->samples_per_ms > 0.0f, "gc_acq_create: bad sizes");
+    GC_REQUIRE(conf->doppler_step > 0, "gc_acq_create: doppler_step must be > 0");
+    gc_device_guard g(ctx->device);
+    gc_acq* a = new gc_acq();
+    a->ctx = ctx;
+    a->conf = *conf;
+    a->n_sats = n_sats;
+    // pcps_acquisition.cc:77-85, :113-117
+    const bool bt = conf->bit_transition_flag != 0;
+    a->consumed = (uint32_t)(conf->sampled_ms * conf->samples_per_ms * (bt ? 2 : 1));
+    a->fft_size = (conf->sampled_ms == conf->ms_per_code) ? a->consumed : a->consumed * 2;
+    a->max_dwells = conf->max_dwells;
+    if (bt)
+        {
+            a->fft_size = a->consumed * 2;
+            a->max_dwells = 1;
+        }
+    a->eff = bt ? a->fft_size / 2 : a->fft_size;
+    // :152-159 CFAR statistic only for a single dwell
+    a->use_cfar = (a->max_dwells == 1) ? (conf->use_CFAR_algorithm_flag != 0) : false;
+    // :326
+    a->n_bins = (uint32_t)std::ceil((double)((int32_t)conf->doppler_max - (int32_t)(-(int32_t)conf->doppler_max)) / (double)conf->doppler_step);
+    if (conf->num_doppler_bins_override > 0) a->n_bins = conf->num_doppler_bins_override;
+    if (a->n_bins == 0 || a->fft_size == 0)
+        {
+            delete a;
+            return gc_fail(GC_ERR_INVALID, "gc_acq_create: empty search grid");
+        }
+    const size_t lds_limit = 160 * 1024;
+    if (!acq_plan_make(&a->plan, (int)a->fft_size, lds_limit))
+        {
+            delete a;
+            return gc_fail(GC_ERR_INVALID, "gc_acq_create: fft_size %u has no supported factorisation", a->fft_size);
+        }
+    const size_t N = a->fft_size;
+    a->n_blocks = acq_cols_blocks(a->plan);
+    // scratch Q: keep a batch of satellites within ~96 MB so that it lives in the Infinity Cache
+    size_t per_sat = (size_t)a->n_bins * N * sizeof(float2);
+    a->sats_per_batch = (int)((96u << 20) / per_sat);
+    if (a->sats_per_batch < 1) a->sats_per_batch = 1;
+    if (a->sats_per_batch > n_sats) a->sats_per_batch = n_sats;
+    size_t q_cells = (size_t)a->sats_per_batch * a->n_bins;
+    if (q_cells < a->n_bins) q_cells = a->n_bins;
+
+    ACQ_TRY(hipMalloc(&a->d_wN, N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_wN2, (size_t)a->plan.N2 * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_wipe, (size_t)a->n_bins * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_codes, (size_t)n_sats * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_xw, (size_t)a->n_bins * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_X, (size_t)a->n_bins * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_Q, q_cells * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_grid, (size_t)n_sats * a->n_bins * N * sizeof(float)));
+    ACQ_TRY(hipMalloc(&a->d_tmp, (size_t)n_sats * N * sizeof(float)));
+    ACQ_TRY(hipMalloc(&a->d_blkv, (size_t)n_sats * a->n_bins * a->n_blocks * sizeof(float)));
+    ACQ_TRY(hipMalloc(&a->d_blki, (size_t)n_sats * a->n_bins * a->n_blocks * sizeof(unsigned)));
+    ACQ_TRY(hipMalloc(&a->d_power, sizeof(float)));
+    ACQ_TRY(hipMalloc(&a->d_in, N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_results, (size_t)n_sats * sizeof(gc_acq_result)));
+    ACQ_TRY(hipHostMalloc(reinterpret_cast<void**>(&a->h_results), (size_t)n_sats * sizeof(gc_acq_result), hipHostMallocDefault));
+    a->code_set.assign(n_sats, 0);
+
+    hipStream_t st = ctx->stream;
+    // twiddle tables, rounded from float64
+    {
+        std::vector<float2> w(N);
+        for (size_t k = 0; k < N; k++)
+            {
+                double ang = -2.0 * M_PI * (double)k / (double)N;
+                w[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+        ACQ_TRY(hipMemcpy(a->d_wN, w.data(), N * sizeof(float2), hipMemcpyHostToDevice));
+        const size_t N2 = a->plan.N2;
+        for (size_t k = 0; k < N2; k++)
+            {
+                double ang = -2.0 * M_PI * (double)k / (double)N2;
+                w[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+        ACQ_TRY(hipMemcpy(a->d_wN2, w.data(), N2 * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    // Doppler wipe-off grid: init() (:340-357) + update_local_carrier (:296-310)
+    {
+        std::vector<float> inc(a->n_bins);
+        for (uint32_t d = 0; d < a->n_bins; d++)
+            {
+                int32_t doppler = -(int32_t)conf->doppler_max + (int32_t)conf->doppler_step * (int32_t)d;
+                float freq = (float)doppler;
+                float phase_step_rad = (float)(6.283185307179586 * freq / (float)conf->fs_in);
+                inc[d] = -phase_step_rad;
+            }
+        float* d_inc = nullptr;
+        ACQ_TRY(hipMalloc(&d_inc, sizeof(float) * a->n_bins));
+        hipError_t e = hipMemcpy(d_inc, inc.data(), sizeof(float) * a->n_bins, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe, (int)a->n_bins, (int)N);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_inc);
+        ACQ_TRY(e);
+    }
+    ACQ_TRY(hipMemsetAsync(a->d_grid, 0, (size_t)n_sats * a->n_bins * N * sizeof(float), st));
+    ACQ_TRY(hipMemsetAsync(a->d_tmp, 0, (size_t)n_sats * N * sizeof(float), st));
+    ACQ_TRY(hipMemsetAsync(a->d_codes, 0, (size_t)n_sats * N * sizeof(float2), st));
+    ACQ_TRY(hipMemsetAsync(a->d_power, 0, sizeof(float), st));
+    ACQ_TRY(hipStreamSynchronize(st));
+    *out = a;
+    return GC_OK;
+}
+
+gc_status gc_acq_destroy(gc_acq* a)
+{
+    if (!a) return GC_OK;
+    gc_device_guard g(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    acq_release(a);
+    delete a;
+    return GC_OK;
+}
+
+gc_status gc_acq_fft_size(const gc_acq* a, uint32_t* fft_size, uint32_t* consumed_samples, uint32_t* num_doppler_bins)
+{
+    GC_REQUIRE(a, "gc_acq_fft_size: NULL handle");
+    if (fft_size) *fft_size = a->fft_size;
+    if (consumed_samples) *consumed_samples = a->consumed;
+    if (num_doppler_bins) *num_doppler_bins = a->n_bins;
+    return GC_OK;
+}
+
+gc_status gc_acq_set_local_code(gc_acq* a, int sat, const float* code)
+{
+    GC_REQUIRE(a && code, "gc_acq_set_local_code: NULL argument");
+    GC_REQUIRE(sat >= 0 && sat < a->n_sats, "gc_acq_set_local_code: satellite slot %d out of range", sat);
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = a->ctx->stream;
+    const size_t N = a->fft_size;
+    // [0 .. 0 c_0 .. c_L] layouts of set_local_code (:252-269)
+    std::vector<float2> buf(N, make_float2(0.f, 0.f));
+    const float2* c = reinterpret_cast<const float2*>(code);
+    if (a->conf.bit_transition_flag)
+        {
+            size_t off = N / 2;
+            std::memcpy(buf.data() + off, c, sizeof(float2) * off);
+        }
+    else if (a->fft_size == a->consumed)
+        std::memcpy(buf.data(), c, sizeof(float2) * a->consumed);
+    else
+        std::memcpy(buf.data() + (N - a->consumed), c, sizeof(float2) * a->consumed);
+    GC_HIP(hipMemcpyAsync(a->d_in, buf.data(), N * sizeof(float2), hipMemcpyHostToDevice, st));
+    // FFT, conjugate (:272-273), kept in the row-permuted layout the inverse rows pass reads
+    hipError_t e = acq_launch_permute(st, a->d_in, nullptr, a->d_xw, a->plan, (int)N, 1, 0, 0, 0);
+    if (e == hipSuccess) e = acq_launch_rows(st, false, a->plan, 1, a->d_xw, AcqCellMap{1, 1}, nullptr, AcqCellMap{1, 1}, a->d_Q, a->d_wN2, a->d_wN);
+    if (e == hipSuccess) e = acq_launch_cols(st, false, ACQ_EPI_COMPLEX_CONJ_PERM, a->plan, 1, a->d_Q, a->d_codes + (size_t)sat * N, nullptr);
+    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_local_code: %s", hipGetErrorString(e));
+    GC_HIP(hipStreamSynchronize(st));  // buf goes out of scope
+    a->code_set[sat] = 1;
+    return GC_OK;
+}
+
+gc_status gc_acq_reset(gc_acq* a)
+{
+    GC_REQUIRE(a, "gc_acq_reset: NULL handle");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    // grid reset (:917-924) and d_num_noncoherent_integrations_counter = 0
+    GC_HIP(hipMemsetAsync(a->d_grid, 0, (size_t)a->n_sats * a->n_bins * a->fft_size * sizeof(float), a->ctx->stream));
+    a->dwell_counter = 0;
+    return GC_OK;
+}
+
+static gc_status acq_enqueue(gc_acq* a, const float2* dev_iq, hipStream_t st)
+{
+    for (int s = 0; s < a->n_sats; s++)
+        if (!a->code_set[s]) return gc_fail(GC_ERR_STATE, "gc_acq_dwell: satellite slot %d has no local code", s);
+    const size_t N = a->fft_size;
+    const int n_bins = (int)a->n_bins;
+    a->dwell_counter++;
+    hipError_t e = hipSuccess;
+    const bool bt = a->conf.bit_transition_flag != 0;
+    if (a->use_cfar || bt)
+        e = acq_launch_input_power(st, dev_iq, (int)a->consumed, (int)N, a->d_power, a->d_tmp, a->n_sats, N);
+    // x * wipeoff[d] for every bin (:717), zero padded to fft_size (:680-688), row-permuted
+    if (e == hipSuccess) e = acq_launch_permute(st, dev_iq, a->d_wipe, a->d_xw, a->plan, (int)a->consumed, n_bins, 0, N, N);
+    // forward FFT per bin (:721), shared by every satellite
+    if (e == hipSuccess) e = acq_launch_rows(st, false, a->plan, n_bins, a->d_xw, AcqCellMap{1, n_bins}, nullptr, AcqCellMap{1, 1}, a->d_Q, a->d_wN2, a->d_wN);
+    if (e == hipSuccess) e = acq_launch_cols(st, false, ACQ_EPI_PERM, a->plan, n_bins, a->d_Q, a->d_X, nullptr);
+    // per satellite and bin: * conj(FFT(code)) (:724), IFFT (:727), |.|^2 (+=) (:730-739)
+    for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += a->sats_per_batch)
+        {
+            const int ns = std::min(a->sats_per_batch, a->n_sats - s0);
+            const int cells = ns * n_bins;
+            e = acq_launch_rows(st, true, a->plan, cells, a->d_X, AcqCellMap{1, n_bins}, a->d_codes + (size_t)s0 * N,
+                AcqCellMap{n_bins, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
+            if (e != hipSuccess) break;
+            AcqMagArgs m;
+            m.grid = a->d_grid + (size_t)s0 * n_bins * N;
+            m.tmp = a->d_tmp + (size_t)s0 * N;
+            m.blk_max_val = a->d_blkv + (size_t)s0 * n_bins * a->n_blocks;
+            m.blk_max_idx = a->d_blki + (size_t)s0 * n_bins * a->n_blocks;
+            m.accumulate = a->dwell_counter > 1 ? 1 : 0;
+            m.offset = bt ? (int)a->eff : 0;
+            m.eff = (int)a->eff;
+            m.n_bins = n_bins;
+            m.tmp_bin = n_bins - 1;
+            e = acq_launch_cols(st, true, ACQ_EPI_MAG, a->plan, cells, a->d_Q, nullptr, &m);
+        }
+    if (e == hipSuccess)
+        {
+            AcqFinalArgs f;
+            f.grid = a->d_grid;
+            f.tmp = a->d_tmp;
+            f.blk_max_val = a->d_blkv;
+            f.blk_max_idx = a->d_blki;
+            f.input_power = (a->use_cfar || bt) ? a->d_power : nullptr;
+            f.results = a->d_results;
+            f.n_bins = n_bins;
+            f.n_blocks = a->n_blocks;
+            f.fft_size = (int)N;
+            f.doppler_max = (int)a->conf.doppler_max;
+            f.doppler_step = (int)a->conf.doppler_step;
+            f.use_cfar = a->use_cfar ? 1 : 0;
+            f.samples_per_chip = (int)a->conf.samples_per_chip;
+            f.samples_per_code = a->conf.samples_per_code;
+            e = acq_launch_final(st, f, a->n_sats);
+        }
+    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: kernel launch failed: %s", hipGetErrorString(e));
+    return GC_OK;
+}
+
+gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream)
+{
+    GC_REQUIRE(a && dev_iq, "gc_acq_dwell_enqueue: NULL argument");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    return acq_enqueue(a, static_cast<const float2*>(dev_iq), gc_pick_stream(a->ctx, stream));
+}
+
+gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* stream)
+{
+    GC_REQUIRE(a && host_results, "gc_acq_fetch_results: NULL argument");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = gc_pick_stream(a->ctx, stream);
+    GC_HIP(hipMemcpyAsync(a->h_results, a->d_results, sizeof(gc_acq_result) * a->n_sats, hipMemcpyDeviceToHost, st));
+    GC_HIP(hipStreamSynchronize(st));
+    std::memcpy(host_results, a->h_results, sizeof(gc_acq_result) * a->n_sats);
+    return GC_OK;
+}
+
+gc_status gc_acq_dwell_dev(gc_acq* a, const void* dev_iq, gc_acq_result* host_results, void* stream)
+{
+    gc_status s = gc_acq_dwell_enqueue(a, dev_iq, stream);
+    if (s != GC_OK) return s;
+    return gc_acq_fetch_results(a, host_results, stream);
+}
+
+gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_results)
+{
+    GC_REQUIRE(a && host_iq && host_results, "gc_acq_dwell: NULL argument");
+    {
+        gc_device_guard g(a->ctx->device);
+        std::lock_guard<std::mutex> lk(a->ctx->mtx);
+        GC_HIP(hipMemcpyAsync(a->d_in, host_iq, sizeof(float2) * a->consumed, hipMemcpyHostToDevice, a->ctx->stream));
+        GC_HIP(hipStreamSynchronize(a->ctx->stream));
+    }
+    return gc_acq_dwell_dev(a, a->d_in, host_results, nullptr);
+}
+
+gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid)
+{
+    GC_REQUIRE(a && host_grid, "gc_acq_get_grid: NULL argument");
+    GC_REQUIRE(sat >= 0 && sat < a->n_sats, "gc_acq_get_grid: satellite slot %d out of range", sat);
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    const size_t n = (size_t)a->n_bins * a->fft_size;
+    GC_HIP(hipStreamSynchronize(a->ctx->stream));
+    GC_HIP(hipMemcpy(host_grid, a->d_grid + (size_t)sat * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    return GC_OK;
+}
+
+}  // extern "C"

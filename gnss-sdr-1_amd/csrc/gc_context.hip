@@ -1,0 +1,85 @@
+// gc_context.hip -- context, error reporting, version (libgnsscorr.so).
+#include "gc_internal.h"
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void gc_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+gc_status gc_fail(gc_status st, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return st;
+}
+
+extern "C" {
+
+const char* gc_last_error(void) { return g_err; }
+
+const char* gc_version(void) { return "gnsscorr 0.1 (gfx950)"; }
+
+int gc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+gc_status gc_ctx_create(int device, gc_ctx** out)
+{
+    GC_REQUIRE(out != nullptr, "gc_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return gc_fail(GC_ERR_NO_DEVICE, "gc_ctx_create: no HIP device is visible; libgnsscorr has no CPU fallback");
+    if (device < 0 || device >= n)
+        return gc_fail(GC_ERR_NO_DEVICE, "gc_ctx_create: device %d out of range (%d visible)", device, n);
+    gc_device_guard g(device);
+    if (!g.ok) return gc_fail(GC_ERR_HIP, "gc_ctx_create: hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    GC_HIP(hipGetDeviceProperties(&prop, device));
+    gc_ctx* c = new gc_ctx();
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    c->lds_max = prop.sharedMemPerBlock;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess)
+        {
+            delete c;
+            return gc_fail(GC_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+    *out = c;
+    return GC_OK;
+}
+
+gc_status gc_ctx_destroy(gc_ctx* ctx)
+{
+    if (!ctx) return GC_OK;
+    gc_device_guard g(ctx->device);
+    if (ctx->stream)
+        {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamDestroy(ctx->stream);
+        }
+    delete ctx;
+    return GC_OK;
+}
+
+gc_status gc_ctx_synchronize(gc_ctx* ctx)
+{
+    GC_REQUIRE(ctx != nullptr, "gc_ctx_synchronize: ctx is NULL");
+    gc_device_guard g(ctx->device);
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+}
+
+}  // extern "C"

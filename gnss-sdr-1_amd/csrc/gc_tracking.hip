@@ -1,0 +1,480 @@
+// gc_tracking.hip -- host side of the tracking path of libgnsscorr.so:
+//   * gc_trk_batch_*   : batched, HBM-resident multi-channel / multi-epoch engine
+//   * gc_correlator_*  : one object per channel with the method set of the
+//                        reference's Cpu_Multicorrelator_Real_Codes
+//                        (src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.h:45-69)
+#include "gc_internal.h"
+#include "trk_kernels.h"
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <vector>
+
+// -----------------------------------------------------------------------------
+// parameter marshalling: same float arithmetic as the reference's call site
+// -----------------------------------------------------------------------------
+extern "C" void gc_epoch_params_fill(gc_epoch_params* p, uint64_t sample_offset,
+    float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    int signal_length_samples)
+{
+    // cpu_multicorrelator_real_codes.cc:141  lv_cmake(std::cos(rem), -std::sin(rem))
+    p->sample_offset = sample_offset;
+    p->phase0_re = std::cos(rem_carrier_phase_in_rad);
+    p->phase0_im = -std::sin(rem_carrier_phase_in_rad);
+    // :145/:149  std::exp(lv_32fc_t(0.0, -phase_step_rad)), std::exp(lv_32fc_t(0.0, -phase_rate_step_rad))
+    const std::complex<float> inc = std::exp(std::complex<float>(0.0f, -phase_step_rad));
+    const std::complex<float> rate = std::exp(std::complex<float>(0.0f, -phase_rate_step_rad));
+    p->phase_inc_re = inc.real();
+    p->phase_inc_im = inc.imag();
+    p->phase_rate_re = rate.real();
+    p->phase_rate_im = rate.imag();
+    p->rem_code_phase_chips = rem_code_phase_chips;
+    p->code_phase_step_chips = code_phase_step_chips;
+    p->code_phase_rate_step_chips = code_phase_rate_step_chips;
+    p->n_samples = signal_length_samples;
+}
+
+// -----------------------------------------------------------------------------
+// batched engine
+// -----------------------------------------------------------------------------
+struct gc_trk_batch
+{
+    gc_ctx* ctx = nullptr;
+    int n_channels = 0, n_taps = 0, max_code_len = 0, mode = TRK_MODE_PLAIN;
+    int lds_table_floats = 0;
+    int nominal_len = 0;
+    int forced_slices = 0;
+    std::vector<TrkChan> h_chans;
+    bool chans_dirty = true;
+    TrkChan* d_chans = nullptr;
+    float* d_codes = nullptr;
+    float2* d_partial = nullptr;
+    size_t partial_cap = 0;
+    gc_epoch_params* d_params = nullptr;
+    size_t params_cap = 0;
+    float2* d_out = nullptr;
+    size_t out_cap = 0;
+};
+
+static const int kMaxLdsTableFloats = 16000;  // 64 KB default dynamic-LDS limit minus the header
+
+static int pick_slices(const gc_trk_batch* b, int n_epochs, int max_len)
+{
+    if (b->forced_slices > 0) return b->forced_slices;
+    // aim at >= 8 workgroups per CU; never cut an epoch below 4 chunks (2048 samples) per slice
+    const long long jobs = (long long)b->n_channels * n_epochs;
+    const long long want = 8LL * (b->ctx->n_cus > 0 ? b->ctx->n_cus : 256);
+    if (jobs >= want || max_len <= 0) return 1;
+    const int chunks = (max_len + 511) / 512;
+    int s = (int)((want + jobs - 1) / jobs);
+    int smax = chunks / 4;
+    if (smax < 1) smax = 1;
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+static gc_status batch_sync_chans(gc_trk_batch* b, hipStream_t st)
+{
+    if (!b->chans_dirty) return GC_OK;
+    GC_HIP(hipMemcpyAsync(b->d_chans, b->h_chans.data(), sizeof(TrkChan) * b->n_channels, hipMemcpyHostToDevice, st));
+    // the host vector may be edited again right after this call returns
+    GC_HIP(hipStreamSynchronize(st));
+    b->chans_dirty = false;
+    return GC_OK;
+}
+
+extern "C" {
+
+gc_status gc_trk_batch_create(gc_ctx* ctx, int n_channels, int n_taps, int max_code_length, int high_dyn,
+    gc_trk_batch** out)
+{
+    GC_REQUIRE(ctx && out, "gc_trk_batch_create: NULL argument");
+    *out = nullptr;
+    GC_REQUIRE(n_channels > 0, "gc_trk_batch_create: n_channels must be > 0");
+    GC_REQUIRE(n_taps >= 1 && n_taps <= GC_MAX_TAPS, "gc_trk_batch_create: n_taps must be in 1..%d", GC_MAX_TAPS);
+    GC_REQUIRE(max_code_length > 0 && max_code_length + 64 <= kMaxLdsTableFloats,
+        "gc_trk_batch_create: max_code_length must be in 1..%d", kMaxLdsTableFloats - 64);
+    gc_device_guard g(ctx->device);
+    gc_trk_batch* b = new gc_trk_batch();
+    b->ctx = ctx;
+    b->n_channels = n_channels;
+    b->n_taps = n_taps;
+    b->max_code_len = max_code_length;
+    b->mode = high_dyn ? TRK_MODE_HD_FULL : TRK_MODE_PLAIN;
+    b->lds_table_floats = max_code_length + 64;
+    b->h_chans.assign(n_channels, TrkChan{});
+    hipError_t e1 = hipMalloc(&b->d_chans, sizeof(TrkChan) * n_channels);
+    hipError_t e2 = hipMalloc(&b->d_codes, sizeof(float) * (size_t)n_channels * max_code_length);
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        {
+            (void)hipFree(b->d_chans);
+            (void)hipFree(b->d_codes);
+            delete b;
+            return gc_fail(GC_ERR_HIP, "gc_trk_batch_create: hipMalloc failed");
+        }
+    (void)hipMemset(b->d_codes, 0, sizeof(float) * (size_t)n_channels * max_code_length);
+    for (int i = 0; i < n_channels; i++)
+        {
+            b->h_chans[i].code = b->d_codes + (size_t)i * max_code_length;
+            b->h_chans[i].code_len = 0;
+        }
+    *out = b;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_destroy(gc_trk_batch* b)
+{
+    if (!b) return GC_OK;
+    gc_device_guard g(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->d_chans);
+    (void)hipFree(b->d_codes);
+    (void)hipFree(b->d_partial);
+    (void)hipFree(b->d_params);
+    (void)hipFree(b->d_out);
+    delete b;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_shifts(gc_trk_batch* b, int ch, const float* shifts_chips)
+{
+    GC_REQUIRE(b && shifts_chips, "gc_trk_batch_set_shifts: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_shifts: channel %d out of range", ch);
+    for (int t = 0; t < b->n_taps; t++) b->h_chans[ch].shifts[t] = shifts_chips[t];
+    b->chans_dirty = true;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int code_length, const float* shifts_chips)
+{
+    GC_REQUIRE(b && code && shifts_chips, "gc_trk_batch_set_code: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_code: channel %d out of range", ch);
+    GC_REQUIRE(code_length > 0 && code_length <= b->max_code_len, "gc_trk_batch_set_code: code_length %d not in 1..%d",
+        code_length, b->max_code_len);
+    gc_device_guard g(b->ctx->device);
+    GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * b->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
+    b->h_chans[ch].code_len = code_length;
+    return gc_trk_batch_set_shifts(b, ch, shifts_chips);
+}
+
+gc_status gc_trk_batch_set_input_dev(gc_trk_batch* b, int ch, const void* dev_iq, uint64_t n_samples)
+{
+    GC_REQUIRE(b && dev_iq, "gc_trk_batch_set_input_dev: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_input_dev: channel %d out of range", ch);
+    GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) & 7) == 0, "gc_trk_batch_set_input_dev: IQ pointer must be 8-byte aligned");
+    b->h_chans[ch].iq = static_cast<const float2*>(dev_iq);
+    b->h_chans[ch].n_iq = n_samples;
+    b->chans_dirty = true;
+    return GC_OK;
+}
+
+// engine tuning knobs (not part of the reference surface)
+gc_status gc_trk_batch_set_nominal_length(gc_trk_batch* b, int n_samples)
+{
+    GC_REQUIRE(b, "gc_trk_batch_set_nominal_length: NULL argument");
+    b->nominal_len = n_samples;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_slices(gc_trk_batch* b, int n_slices)
+{
+    GC_REQUIRE(b && n_slices >= 0 && n_slices <= 1024, "gc_trk_batch_set_slices: bad argument");
+    b->forced_slices = n_slices;
+    return GC_OK;
+}
+
+static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_params* dev_params, void* dev_out,
+    hipStream_t st, int max_len)
+{
+    for (int i = 0; i < b->n_channels; i++)
+        {
+            GC_REQUIRE(b->h_chans[i].code_len > 0, "gc_trk_batch_run: channel %d has no code (gc_trk_batch_set_code)", i);
+            GC_REQUIRE(b->h_chans[i].iq != nullptr, "gc_trk_batch_run: channel %d has no input (gc_trk_batch_set_input_dev)", i);
+        }
+    gc_status s = batch_sync_chans(b, st);
+    if (s != GC_OK) return s;
+    const int n_slices = pick_slices(b, n_epochs, max_len > 0 ? max_len : b->nominal_len);
+    if (n_slices > 1)
+        {
+            size_t need = (size_t)b->n_channels * n_epochs * n_slices * b->n_taps;
+            if (need > b->partial_cap)
+                {
+                    GC_HIP(hipStreamSynchronize(st));
+                    (void)hipFree(b->d_partial);
+                    b->d_partial = nullptr;
+                    b->partial_cap = 0;
+                    GC_HIP(hipMalloc(&b->d_partial, need * sizeof(float2)));
+                    b->partial_cap = need;
+                }
+        }
+    hipError_t e = trk_launch(b->n_taps, b->mode, st, b->d_chans, dev_params, static_cast<float2*>(dev_out), b->d_partial,
+        b->n_channels, n_epochs, n_slices, b->lds_table_floats);
+    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_run_dev(gc_trk_batch* b, int n_epochs, const gc_epoch_params* dev_params, void* dev_out, void* stream)
+{
+    GC_REQUIRE(b && dev_params && dev_out, "gc_trk_batch_run_dev: NULL argument");
+    GC_REQUIRE(n_epochs > 0, "gc_trk_batch_run_dev: n_epochs must be > 0");
+    gc_device_guard g(b->ctx->device);
+    std::lock_guard<std::mutex> lk(b->ctx->mtx);
+    return batch_launch(b, n_epochs, dev_params, dev_out, gc_pick_stream(b->ctx, stream), 0);
+}
+
+gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params* host_params, float* host_out)
+{
+    GC_REQUIRE(b && host_params && host_out, "gc_trk_batch_run: NULL argument");
+    GC_REQUIRE(n_epochs > 0, "gc_trk_batch_run: n_epochs must be > 0");
+    gc_device_guard g(b->ctx->device);
+    std::lock_guard<std::mutex> lk(b->ctx->mtx);
+    const size_t jobs = (size_t)b->n_channels * n_epochs;
+    int max_len = 0;
+    for (size_t j = 0; j < jobs; j++)
+        {
+            const gc_epoch_params& p = host_params[j];
+            const TrkChan& c = b->h_chans[j / n_epochs];
+            GC_REQUIRE(p.n_samples >= 0, "gc_trk_batch_run: job %zu has negative n_samples", j);
+            GC_REQUIRE(p.sample_offset + (uint64_t)p.n_samples <= c.n_iq,
+                "gc_trk_batch_run: job %zu window [%llu, +%d) exceeds the channel's %llu samples", j,
+                (unsigned long long)p.sample_offset, p.n_samples, (unsigned long long)c.n_iq);
+            if (p.n_samples > max_len) max_len = p.n_samples;
+        }
+    hipStream_t st = b->ctx->stream;
+    if (jobs > b->params_cap)
+        {
+            (void)hipFree(b->d_params);
+            b->d_params = nullptr;
+            b->params_cap = 0;
+            GC_HIP(hipMalloc(&b->d_params, jobs * sizeof(gc_epoch_params)));
+            b->params_cap = jobs;
+        }
+    if (jobs * b->n_taps > b->out_cap)
+        {
+            (void)hipFree(b->d_out);
+            b->d_out = nullptr;
+            b->out_cap = 0;
+            GC_HIP(hipMalloc(&b->d_out, jobs * b->n_taps * sizeof(float2)));
+            b->out_cap = jobs * b->n_taps;
+        }
+    GC_HIP(hipMemcpyAsync(b->d_params, host_params, jobs * sizeof(gc_epoch_params), hipMemcpyHostToDevice, st));
+    gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len);
+    if (s != GC_OK) return s;
+    GC_HIP(hipMemcpyAsync(host_out, b->d_out, jobs * b->n_taps * sizeof(float2), hipMemcpyDeviceToHost, st));
+    GC_HIP(hipStreamSynchronize(st));
+    return GC_OK;
+}
+
+}  // extern "C"
+
+// -----------------------------------------------------------------------------
+// Level 1: Cpu_Multicorrelator_Real_Codes image
+// -----------------------------------------------------------------------------
+struct gc_correlator
+{
+    gc_ctx* ctx = nullptr;
+    bool use_high_dynamics_resampler = true;  // reference ctor default (cpu_multicorrelator_real_codes.cc:49)
+    bool inited = false;
+    int max_len = 0, n_corr = 0;
+    // retained caller pointers (the reference stores pointers, .cc:79-98)
+    const float* local_code_in = nullptr;
+    float* shifts_chips = nullptr;
+    int code_length_chips = 0;
+    float* corr_out = nullptr;
+    const float* sig_in = nullptr;
+    // device side
+    float2* d_sig = nullptr;
+    float* d_code = nullptr;
+    int d_code_cap = 0;
+    std::vector<float> code_shadow;  // last uploaded code contents
+    struct Staging
+    {
+        TrkChan chan;
+        gc_epoch_params params;
+    };
+    Staging* h_stage = nullptr;  // pinned
+    Staging* d_stage = nullptr;
+    float2* d_out = nullptr;
+    float2* h_out = nullptr;  // pinned
+    float2* d_partial = nullptr;
+    int partial_slices = 0;
+};
+
+static void correlator_release(gc_correlator* c)
+{
+    (void)hipFree(c->d_sig);
+    (void)hipFree(c->d_code);
+    (void)hipFree(c->d_stage);
+    (void)hipFree(c->d_out);
+    (void)hipFree(c->d_partial);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    c->d_sig = nullptr;
+    c->d_code = nullptr;
+    c->d_stage = nullptr;
+    c->d_out = nullptr;
+    c->d_partial = nullptr;
+    c->h_stage = nullptr;
+    c->h_out = nullptr;
+    c->d_code_cap = 0;
+    c->code_shadow.clear();
+    c->inited = false;
+}
+
+static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, float phase_step, float phase_rate_step,
+    float rem_code, float code_step, float code_rate_step, int N)
+{
+    GC_REQUIRE(c, "correlator: NULL handle");
+    if (!c->inited) return gc_fail(GC_ERR_STATE, "correlator: init() has not been called");
+    if (!c->local_code_in || !c->shifts_chips) return gc_fail(GC_ERR_STATE, "correlator: set_local_code_and_taps() has not been called");
+    if (!c->corr_out || !c->sig_in) return gc_fail(GC_ERR_STATE, "correlator: set_input_output_vectors() has not been called");
+    GC_REQUIRE(N >= 0 && N <= c->max_len, "correlator: signal_length_samples %d exceeds init() capacity %d", N, c->max_len);
+    GC_REQUIRE(c->code_length_chips > 0 && c->code_length_chips + 64 <= kMaxLdsTableFloats,
+        "correlator: code_length_chips %d not supported (max %d)", c->code_length_chips, kMaxLdsTableFloats - 64);
+    gc_device_guard g(c->ctx->device);
+    std::lock_guard<std::mutex> lk(c->ctx->mtx);
+    hipStream_t st = c->ctx->stream;
+    const int L = c->code_length_chips;
+    // code table: the caller's buffer is re-read on every call like the reference
+    // does; it is re-uploaded only when its contents changed
+    if (L > c->d_code_cap)
+        {
+            (void)hipFree(c->d_code);
+            c->d_code = nullptr;
+            c->d_code_cap = 0;
+            GC_HIP(hipMalloc(&c->d_code, sizeof(float) * L));
+            c->d_code_cap = L;
+            c->code_shadow.clear();
+        }
+    if ((int)c->code_shadow.size() != L || std::memcmp(c->code_shadow.data(), c->local_code_in, sizeof(float) * L) != 0)
+        {
+            c->code_shadow.assign(c->local_code_in, c->local_code_in + L);
+            GC_HIP(hipMemcpyAsync(c->d_code, c->code_shadow.data(), sizeof(float) * L, hipMemcpyHostToDevice, st));
+        }
+    if (N > 0) GC_HIP(hipMemcpyAsync(c->d_sig, c->sig_in, sizeof(float2) * (size_t)N, hipMemcpyHostToDevice, st));
+    gc_correlator::Staging* s = c->h_stage;
+    std::memset(&s->chan, 0, sizeof s->chan);
+    s->chan.iq = c->d_sig;
+    s->chan.n_iq = (unsigned long long)N;
+    s->chan.code = c->d_code;
+    s->chan.code_len = L;
+    for (int t = 0; t < c->n_corr; t++) s->chan.shifts[t] = c->shifts_chips[t];
+    gc_epoch_params_fill(&s->params, 0, rem_carr, phase_step, phase_rate_step, rem_code, code_step, code_rate_step, N);
+    GC_HIP(hipMemcpyAsync(c->d_stage, s, sizeof *s, hipMemcpyHostToDevice, st));
+    // one epoch only: cut it in slices so that the launch covers many CUs
+    int chunks = (N + 1 + 511) / 512;
+    int n_slices = chunks / 2;
+    if (n_slices < 1) n_slices = 1;
+    if (n_slices > c->partial_slices) n_slices = c->partial_slices;
+    hipError_t e = trk_launch(c->n_corr, mode, st, &c->d_stage->chan, &c->d_stage->params, c->d_out, c->d_partial, 1, 1,
+        n_slices, L + 64);
+    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
+    GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, sizeof(float2) * c->n_corr, hipMemcpyDeviceToHost, st));
+    GC_HIP(hipStreamSynchronize(st));
+    std::memcpy(c->corr_out, c->h_out, sizeof(float2) * c->n_corr);
+    return GC_OK;
+}
+
+extern "C" {
+
+gc_status gc_correlator_create(gc_ctx* ctx, gc_correlator** out)
+{
+    GC_REQUIRE(ctx && out, "gc_correlator_create: NULL argument");
+    gc_correlator* c = new gc_correlator();
+    c->ctx = ctx;
+    *out = c;
+    return GC_OK;
+}
+
+gc_status gc_correlator_destroy(gc_correlator* c)
+{
+    if (!c) return GC_OK;
+    gc_device_guard g(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    correlator_release(c);
+    delete c;
+    return GC_OK;
+}
+
+gc_status gc_correlator_set_high_dynamics_resampler(gc_correlator* c, int use_high_dynamics_resampler)
+{
+    GC_REQUIRE(c, "gc_correlator_set_high_dynamics_resampler: NULL handle");
+    c->use_high_dynamics_resampler = use_high_dynamics_resampler != 0;
+    return GC_OK;
+}
+
+gc_status gc_correlator_init(gc_correlator* c, int max_signal_length_samples, int n_correlators)
+{
+    GC_REQUIRE(c, "gc_correlator_init: NULL handle");
+    GC_REQUIRE(max_signal_length_samples > 0, "gc_correlator_init: max_signal_length_samples must be > 0");
+    GC_REQUIRE(n_correlators >= 1 && n_correlators <= GC_MAX_TAPS, "gc_correlator_init: n_correlators must be in 1..%d", GC_MAX_TAPS);
+    gc_device_guard g(c->ctx->device);
+    std::lock_guard<std::mutex> lk(c->ctx->mtx);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    correlator_release(c);
+    c->max_len = max_signal_length_samples;
+    c->n_corr = n_correlators;
+    c->partial_slices = 64;
+    GC_HIP(hipMalloc(&c->d_sig, sizeof(float2) * ((size_t)max_signal_length_samples + 2)));
+    GC_HIP(hipMalloc(&c->d_stage, sizeof(gc_correlator::Staging)));
+    GC_HIP(hipMalloc(&c->d_out, sizeof(float2) * GC_MAX_TAPS));
+    GC_HIP(hipMalloc(&c->d_partial, sizeof(float2) * GC_MAX_TAPS * c->partial_slices));
+    GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), sizeof(gc_correlator::Staging), hipHostMallocDefault));
+    GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_out), sizeof(float2) * GC_MAX_TAPS, hipHostMallocDefault));
+    c->inited = true;
+    return GC_OK;
+}
+
+gc_status gc_correlator_set_local_code_and_taps(gc_correlator* c, int code_length_chips, const float* local_code_in,
+    float* shifts_chips)
+{
+    GC_REQUIRE(c, "gc_correlator_set_local_code_and_taps: NULL handle");
+    c->local_code_in = local_code_in;
+    c->shifts_chips = shifts_chips;
+    c->code_length_chips = code_length_chips;
+    return GC_OK;
+}
+
+gc_status gc_correlator_set_input_output_vectors(gc_correlator* c, float* corr_out, const float* sig_in)
+{
+    GC_REQUIRE(c, "gc_correlator_set_input_output_vectors: NULL handle");
+    c->sig_in = sig_in;
+    c->corr_out = corr_out;
+    return GC_OK;
+}
+
+gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler(gc_correlator* c,
+    float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    int signal_length_samples)
+{
+    GC_REQUIRE(c, "gc_correlator_carrier_wipeoff_multicorrelator_resampler: NULL handle");
+    const int mode = c->use_high_dynamics_resampler ? TRK_MODE_HD_FULL : TRK_MODE_PLAIN;
+    return correlator_run(c, mode, rem_carrier_phase_in_rad, phase_step_rad, phase_rate_step_rad, rem_code_phase_chips,
+        code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples);
+}
+
+gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(gc_correlator* c,
+    float rem_carrier_phase_in_rad, float phase_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    int signal_length_samples)
+{
+    GC_REQUIRE(c, "gc_correlator_carrier_wipeoff_multicorrelator_resampler_6: NULL handle");
+    const int mode = c->use_high_dynamics_resampler ? TRK_MODE_HD_RESAMPLER : TRK_MODE_PLAIN;
+    return correlator_run(c, mode, rem_carrier_phase_in_rad, phase_step_rad, 0.0f, rem_code_phase_chips,
+        code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples);
+}
+
+gc_status gc_correlator_free(gc_correlator* c)
+{
+    GC_REQUIRE(c, "gc_correlator_free: NULL handle");
+    gc_device_guard g(c->ctx->device);
+    std::lock_guard<std::mutex> lk(c->ctx->mtx);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    correlator_release(c);
+    return GC_OK;
+}
+
+}  // extern "C"

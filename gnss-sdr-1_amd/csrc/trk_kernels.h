@@ -1,0 +1,34 @@
+// trk_kernels.h -- device-side descriptors and launcher of the tracking kernel.
+#ifndef TRK_KERNELS_H
+#define TRK_KERNELS_H
+#include "gnsscorr.h"
+#include <hip/hip_runtime.h>
+
+#define GC_MAX_TAPS 8
+
+// per-channel descriptor (device memory)
+struct TrkChan
+{
+    const float2* iq;          // IQ base of the channel's RF stream (HBM)
+    unsigned long long n_iq;   // samples available at iq
+    const float* code;         // code table (HBM), code_len floats
+    int code_len;
+    int reserved;
+    float shifts[GC_MAX_TAPS]; // tap shifts in code samples
+};
+
+enum
+{
+    TRK_MODE_PLAIN = 0,        // resampler_32f_xn + rotator_dot_prod_32fc_xn
+    TRK_MODE_HD_RESAMPLER = 1, // high-dynamics resampler + plain rotator (6-argument overload with the flag set)
+    TRK_MODE_HD_FULL = 2       // high-dynamics resampler + high-dynamic rotator
+};
+
+// Enqueues the multicorrelator for n_channels x n_epochs jobs on `st`.
+// lds_table_floats: capacity of the LDS code window (>= longest code_len).
+// partial: workspace of n_channels*n_epochs*n_slices*n_taps float2 (n_slices > 1 only).
+hipError_t trk_launch(int n_taps, int mode, hipStream_t st, const TrkChan* chans,
+    const gc_epoch_params* params, float2* out, float2* partial,
+    int n_channels, int n_epochs, int n_slices, int lds_table_floats);
+
+#endif

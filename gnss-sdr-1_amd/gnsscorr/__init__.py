@@ -1,0 +1,400 @@
+"""gnsscorr -- ctypes binding of libgnsscorr.so (include/gnsscorr.h).
+
+The product is the C-ABI HIP library; this module only marshals numpy arrays
+and raw device pointers (e.g. ``torch.Tensor.data_ptr()``) into it for tests
+and the benchmark.  There is no CPU fallback: every compute entry point needs
+the HIP library and a GPU, and raises ``GnsscorrError`` otherwise.
+
+Class and method names follow the reference
+(``Cpu_Multicorrelator_Real_Codes`` -> :class:`HipMulticorrelatorRealCodes`,
+``pcps_acquisition`` -> :class:`PcpsAcquisition`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgnsscorr.so")
+
+GC_OK, GC_ERR_INVALID, GC_ERR_NO_DEVICE, GC_ERR_HIP, GC_ERR_STATE = range(5)
+GC_MAX_TAPS = 8
+
+
+class GnsscorrError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("gnsscorr status %d: %s" % (status, msg))
+        self.status = status
+
+
+class EpochParams(C.Structure):
+    """gc_epoch_params (include/gnsscorr.h)."""
+    _fields_ = [
+        ("sample_offset", C.c_uint64),
+        ("phase0_re", C.c_float), ("phase0_im", C.c_float),
+        ("phase_inc_re", C.c_float), ("phase_inc_im", C.c_float),
+        ("phase_rate_re", C.c_float), ("phase_rate_im", C.c_float),
+        ("rem_code_phase_chips", C.c_float),
+        ("code_phase_step_chips", C.c_float),
+        ("code_phase_rate_step_chips", C.c_float),
+        ("n_samples", C.c_int32),
+    ]
+
+
+EPOCH_DTYPE = np.dtype([
+    ("sample_offset", np.uint64),
+    ("phase0_re", np.float32), ("phase0_im", np.float32),
+    ("phase_inc_re", np.float32), ("phase_inc_im", np.float32),
+    ("phase_rate_re", np.float32), ("phase_rate_im", np.float32),
+    ("rem_code_phase_chips", np.float32),
+    ("code_phase_step_chips", np.float32),
+    ("code_phase_rate_step_chips", np.float32),
+    ("n_samples", np.int32),
+], align=True)
+assert EPOCH_DTYPE.itemsize == C.sizeof(EpochParams) == 48
+
+
+class AcqConf(C.Structure):
+    """gc_acq_conf: the Acq_Conf fields pcps_acquisition reads."""
+    _fields_ = [
+        ("fs_in", C.c_int64),
+        ("sampled_ms", C.c_uint32),
+        ("ms_per_code", C.c_uint32),
+        ("samples_per_ms", C.c_float),
+        ("samples_per_code", C.c_float),
+        ("samples_per_chip", C.c_uint32),
+        ("doppler_max", C.c_uint32),
+        ("doppler_step", C.c_uint32),
+        ("max_dwells", C.c_uint32),
+        ("bit_transition_flag", C.c_int32),
+        ("use_CFAR_algorithm_flag", C.c_int32),
+        ("num_doppler_bins_override", C.c_uint32),
+    ]
+
+
+class AcqResult(C.Structure):
+    """gc_acq_result."""
+    _fields_ = [
+        ("indext", C.c_uint32),
+        ("doppler_hz", C.c_int32),
+        ("doppler_index", C.c_uint32),
+        ("test_statistics", C.c_float),
+        ("mag", C.c_float),
+        ("input_power", C.c_float),
+        ("second_peak", C.c_float),
+        ("second_peak_full_row", C.c_float),
+        ("acq_delay_samples", C.c_double),
+        ("acq_doppler_hz", C.c_double),
+    ]
+
+
+# every symbol include/gnsscorr.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_fp = C.POINTER(C.c_float)
+API = {
+    "gc_last_error": (C.c_char_p, []),
+    "gc_version": (C.c_char_p, []),
+    "gc_device_count": (C.c_int, []),
+    "gc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "gc_ctx_destroy": (C.c_int, [_vp]),
+    "gc_ctx_synchronize": (C.c_int, [_vp]),
+    "gc_correlator_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "gc_correlator_destroy": (C.c_int, [_vp]),
+    "gc_correlator_set_high_dynamics_resampler": (C.c_int, [_vp, C.c_int]),
+    "gc_correlator_init": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "gc_correlator_set_local_code_and_taps": (C.c_int, [_vp, C.c_int, _fp, _fp]),
+    "gc_correlator_set_input_output_vectors": (C.c_int, [_vp, _fp, _fp]),
+    "gc_correlator_carrier_wipeoff_multicorrelator_resampler": (C.c_int, [_vp] + [C.c_float] * 6 + [C.c_int]),
+    "gc_correlator_carrier_wipeoff_multicorrelator_resampler_6": (C.c_int, [_vp] + [C.c_float] * 5 + [C.c_int]),
+    "gc_correlator_free": (C.c_int, [_vp]),
+    "gc_epoch_params_fill": (None, [C.POINTER(EpochParams), C.c_uint64] + [C.c_float] * 6 + [C.c_int]),
+    "gc_trk_batch_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "gc_trk_batch_destroy": (C.c_int, [_vp]),
+    "gc_trk_batch_set_code": (C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp]),
+    "gc_trk_batch_set_shifts": (C.c_int, [_vp, C.c_int, _fp]),
+    "gc_trk_batch_set_input_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
+    "gc_trk_batch_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "gc_trk_batch_run": (C.c_int, [_vp, C.c_int, _vp, _fp]),
+    "gc_trk_batch_set_nominal_length": (C.c_int, [_vp, C.c_int]),
+    "gc_trk_batch_set_slices": (C.c_int, [_vp, C.c_int]),
+    "gc_acq_create": (C.c_int, [_vp, C.POINTER(AcqConf), C.c_int, C.POINTER(_vp)]),
+    "gc_acq_destroy": (C.c_int, [_vp]),
+    "gc_acq_fft_size": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gc_acq_set_local_code": (C.c_int, [_vp, C.c_int, _fp]),
+    "gc_acq_reset": (C.c_int, [_vp]),
+    "gc_acq_dwell_dev": (C.c_int, [_vp, _vp, C.POINTER(AcqResult), _vp]),
+    "gc_acq_dwell": (C.c_int, [_vp, _fp, C.POINTER(AcqResult)]),
+    "gc_acq_dwell_enqueue": (C.c_int, [_vp, _vp, _vp]),
+    "gc_acq_fetch_results": (C.c_int, [_vp, C.POINTER(AcqResult), _vp]),
+    "gc_acq_get_grid": (C.c_int, [_vp, C.c_int, _fp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libgnsscorr.so (built by gnss-sdr-1_amd/csrc/Makefile).  Raises
+    when it is missing: the HIP library IS the product."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GnsscorrError(GC_ERR_NO_DEVICE, "%s not built (run __graft_entry__.build())" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+        # libamdhip64.so.7.  When torch is going to share the process (device
+        # buffers for tests/bench) it must be loaded first, so that this library
+        # binds to the same runtime instead of /opt/rocm's copy.
+        if os.environ.get("GNSSCORR_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in API.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(st):
+    if st != GC_OK:
+        raise GnsscorrError(st, load_library().gc_last_error().decode())
+
+
+def _f32p(a):
+    return a.ctypes.data_as(_fp)
+
+
+def device_count():
+    return load_library().gc_device_count()
+
+
+def epoch_params(sample_offset, rem_carr_phase_rad, carr_phase_step_rad, rem_code_phase_chips,
+        code_phase_step_chips, n_samples, carr_phase_rate_step_rad=0.0, code_phase_rate_step_chips=0.0):
+    """gc_epoch_params_fill: the reference's scalar arguments -> kernel arguments
+    (cpu_multicorrelator_real_codes.cc:141-149)."""
+    p = EpochParams()
+    load_library().gc_epoch_params_fill(C.byref(p), int(sample_offset), rem_carr_phase_rad, carr_phase_step_rad,
+        carr_phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, int(n_samples))
+    return p
+
+
+def epoch_params_array(records):
+    """list (or nested list [ch][epoch]) of EpochParams -> numpy structured array."""
+    flat = []
+    for r in records:
+        if isinstance(r, (list, tuple)):
+            flat.extend(r)
+        else:
+            flat.append(r)
+    out = np.zeros(len(flat), EPOCH_DTYPE)
+    for i, p in enumerate(flat):
+        out[i] = np.frombuffer(bytes(p), EPOCH_DTYPE)[0]
+    return out
+
+
+class Context:
+    """gc_ctx: one per GPU."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        _check(load_library().gc_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):
+        _check(load_library().gc_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            load_library().gc_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipMulticorrelatorRealCodes:
+    """Image of Cpu_Multicorrelator_Real_Codes
+    (src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.h:45-69): same
+    methods, same argument meaning, pointers retained not copied, every method
+    returns True."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._h = _vp()
+        _check(load_library().gc_correlator_create(ctx._h, C.byref(self._h)))
+        self._keep = {}
+
+    def set_high_dynamics_resampler(self, use_high_dynamics_resampler):
+        _check(load_library().gc_correlator_set_high_dynamics_resampler(self._h, int(bool(use_high_dynamics_resampler))))
+
+    def init(self, max_signal_length_samples, n_correlators):
+        _check(load_library().gc_correlator_init(self._h, max_signal_length_samples, n_correlators))
+        return True
+
+    def set_local_code_and_taps(self, code_length_chips, local_code_in, shifts_chips):
+        assert local_code_in.dtype == np.float32 and shifts_chips.dtype == np.float32
+        self._keep["code"] = local_code_in
+        self._keep["shifts"] = shifts_chips
+        _check(load_library().gc_correlator_set_local_code_and_taps(self._h, code_length_chips, _f32p(local_code_in), _f32p(shifts_chips)))
+        return True
+
+    def set_input_output_vectors(self, corr_out, sig_in):
+        assert corr_out.dtype == np.complex64 and sig_in.dtype == np.complex64
+        self._keep["out"] = corr_out
+        self._keep["in"] = sig_in
+        _check(load_library().gc_correlator_set_input_output_vectors(self._h,
+            corr_out.view(np.float32).ctypes.data_as(_fp), sig_in.view(np.float32).ctypes.data_as(_fp)))
+        return True
+
+    def Carrier_wipeoff_multicorrelator_resampler(self, rem_carrier_phase_in_rad, phase_step_rad, *rest):
+        """7-argument form (…, phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips,
+        code_phase_rate_step_chips, signal_length_samples) or the 6-argument overload without
+        phase_rate_step_rad, as in the reference (.cc:129-170)."""
+        lib = load_library()
+        if len(rest) == 5:
+            rate, rem_code, code_step, code_rate, n = rest
+            _check(lib.gc_correlator_carrier_wipeoff_multicorrelator_resampler(self._h, rem_carrier_phase_in_rad,
+                phase_step_rad, rate, rem_code, code_step, code_rate, int(n)))
+        elif len(rest) == 4:
+            rem_code, code_step, code_rate, n = rest
+            _check(lib.gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(self._h, rem_carrier_phase_in_rad,
+                phase_step_rad, rem_code, code_step, code_rate, int(n)))
+        else:
+            raise TypeError("expected 6 or 7 arguments")
+        return True
+
+    def free(self):
+        _check(load_library().gc_correlator_free(self._h))
+        return True
+
+    def close(self):
+        if self._h:
+            load_library().gc_correlator_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TrackingBatch:
+    """gc_trk_batch: all channels of one GPU, many epochs per launch."""
+
+    def __init__(self, ctx, n_channels, n_taps, max_code_length, high_dyn=False):
+        self._ctx = ctx
+        self.n_channels, self.n_taps = n_channels, n_taps
+        self._h = _vp()
+        _check(load_library().gc_trk_batch_create(ctx._h, n_channels, n_taps, max_code_length, int(high_dyn), C.byref(self._h)))
+
+    def set_code(self, ch, code, shifts_chips):
+        code = np.ascontiguousarray(code, np.float32)
+        shifts = np.ascontiguousarray(shifts_chips, np.float32)
+        assert shifts.size == self.n_taps
+        _check(load_library().gc_trk_batch_set_code(self._h, ch, _f32p(code), code.size, _f32p(shifts)))
+
+    def set_shifts(self, ch, shifts_chips):
+        shifts = np.ascontiguousarray(shifts_chips, np.float32)
+        assert shifts.size == self.n_taps
+        _check(load_library().gc_trk_batch_set_shifts(self._h, ch, _f32p(shifts)))
+
+    def set_input_dev(self, ch, dev_ptr, n_samples):
+        _check(load_library().gc_trk_batch_set_input_dev(self._h, ch, _vp(dev_ptr), int(n_samples)))
+
+    def set_nominal_length(self, n):
+        _check(load_library().gc_trk_batch_set_nominal_length(self._h, int(n)))
+
+    def set_slices(self, n):
+        _check(load_library().gc_trk_batch_set_slices(self._h, int(n)))
+
+    def run_dev(self, n_epochs, dev_params_ptr, dev_out_ptr, stream=None):
+        _check(load_library().gc_trk_batch_run_dev(self._h, n_epochs, _vp(dev_params_ptr), _vp(dev_out_ptr), _vp(stream or 0)))
+
+    def run(self, n_epochs, params):
+        """params: structured array (EPOCH_DTYPE) of n_channels*n_epochs records, channel-major.
+        Returns complex64 [n_channels, n_epochs, n_taps]."""
+        params = np.ascontiguousarray(params, EPOCH_DTYPE)
+        assert params.size == self.n_channels * n_epochs
+        out = np.zeros((self.n_channels, n_epochs, self.n_taps), np.complex64)
+        _check(load_library().gc_trk_batch_run(self._h, n_epochs, params.ctypes.data_as(_vp), out.view(np.float32).ctypes.data_as(_fp)))
+        return out
+
+    def close(self):
+        if self._h:
+            load_library().gc_trk_batch_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PcpsAcquisition:
+    """gc_acq: pcps_acquisition (pcps_acquisition.cc) for n_sats satellites that
+    search the same input block."""
+
+    def __init__(self, ctx, n_sats, fs_in, sampled_ms, ms_per_code, samples_per_ms, samples_per_code, samples_per_chip,
+            doppler_max, doppler_step, max_dwells=1, bit_transition_flag=False, use_cfar=True, num_doppler_bins_override=0):
+        self._ctx = ctx
+        self.n_sats = n_sats
+        conf = AcqConf(int(fs_in), sampled_ms, ms_per_code, samples_per_ms, samples_per_code, samples_per_chip,
+            doppler_max, doppler_step, max_dwells, int(bit_transition_flag), int(use_cfar), num_doppler_bins_override)
+        self.conf = conf
+        self._h = _vp()
+        _check(load_library().gc_acq_create(ctx._h, C.byref(conf), n_sats, C.byref(self._h)))
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(load_library().gc_acq_fft_size(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.fft_size, self.consumed_samples, self.num_doppler_bins = a.value, b.value, c.value
+
+    def set_local_code(self, sat, code):
+        code = np.ascontiguousarray(code, np.complex64)
+        need = self.fft_size // 2 if self.conf.bit_transition_flag else self.consumed_samples
+        assert code.size >= need, (code.size, need)
+        _check(load_library().gc_acq_set_local_code(self._h, sat, code.view(np.float32).ctypes.data_as(_fp)))
+
+    def reset(self):
+        _check(load_library().gc_acq_reset(self._h))
+
+    def dwell(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        assert iq.size >= self.consumed_samples
+        res = (AcqResult * self.n_sats)()
+        _check(load_library().gc_acq_dwell(self._h, iq.view(np.float32).ctypes.data_as(_fp), res))
+        return list(res)
+
+    def dwell_dev(self, dev_ptr, stream=None):
+        res = (AcqResult * self.n_sats)()
+        _check(load_library().gc_acq_dwell_dev(self._h, _vp(dev_ptr), res, _vp(stream or 0)))
+        return list(res)
+
+    def dwell_enqueue(self, dev_ptr, stream=None):
+        _check(load_library().gc_acq_dwell_enqueue(self._h, _vp(dev_ptr), _vp(stream or 0)))
+
+    def fetch_results(self, stream=None):
+        res = (AcqResult * self.n_sats)()
+        _check(load_library().gc_acq_fetch_results(self._h, res, _vp(stream or 0)))
+        return list(res)
+
+    def grid(self, sat):
+        g = np.zeros((self.num_doppler_bins, self.fft_size), np.float32)
+        _check(load_library().gc_acq_get_grid(self._h, sat, _f32p(g)))
+        return g
+
+    def close(self):
+        if self._h:
+            load_library().gc_acq_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,223 @@
+/*
+ * gnsscorr.h -- C ABI of libgnsscorr.so, the MI355X (gfx950, HIP) acquisition +
+ * tracking correlator engine.
+ *
+ * This is the drop-in boundary for ONE path of GNSS-SDR (zhufengGNSS/gnss-sdr-1):
+ *
+ *   tracking   Cpu_Multicorrelator_Real_Codes                      (reference:
+ *              src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.h:45-69)
+ *              = volk_gnsssdr_32f_xn_resampler_32f_xn               (code NCO)
+ *              + volk_gnsssdr_32fc_32f_rotator_dot_prod_32fc_xn     (carrier NCO + E/P/L)
+ *   acquisition pcps_acquisition                                    (reference:
+ *              src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.h:81-261,
+ *              .cc:239-274 set_local_code, :313-368 init, :668-927 acquisition_core)
+ *
+ * Conventions: plain C types only (no C++/torch types); every function returns
+ * a gc_status (0 = ok) and records a message readable with gc_last_error();
+ * no exception crosses the ABI.  "host" pointers are caller-owned host memory,
+ * "dev" pointers are caller-owned device (HBM) memory on the context's GPU.
+ * Complex values are interleaved float32 (re, im), i.e. std::complex<float> /
+ * gr_complex / lv_32fc_t.  A `stream` argument is a hipStream_t passed as
+ * void* (NULL = the context's own stream).  The library fails loudly
+ * (GC_ERR_NO_DEVICE) when no HIP device is usable: there is no CPU fallback.
+ *
+ * The C++ classes in gnss-sdr-1_amd/adapter/ (Hip_Multicorrelator_Real_Codes,
+ * hip_pcps_acquisition, the TrackingInterface/AcquisitionInterface-shaped
+ * adapters) are thin inline wrappers over these entry points; INTEGRATION.md
+ * shows the binding a GNSS-SDR maintainer adds.
+ */
+#ifndef GNSSCORR_H
+#define GNSSCORR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int gc_status;
+enum
+{
+    GC_OK = 0,
+    GC_ERR_INVALID = 1,   /* bad argument / shape */
+    GC_ERR_NO_DEVICE = 2, /* no usable HIP device (no CPU fallback exists) */
+    GC_ERR_HIP = 3,       /* a HIP runtime call failed */
+    GC_ERR_STATE = 4      /* call sequence error (e.g. correlate before init) */
+};
+
+/* Last error message of the calling thread ("" when none). */
+const char* gc_last_error(void);
+/* Library version string. */
+const char* gc_version(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int gc_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Context: one per GPU.  Owns a HIP stream and scratch buffers.             */
+/* ------------------------------------------------------------------------ */
+typedef struct gc_ctx gc_ctx;
+gc_status gc_ctx_create(int device, gc_ctx** out);
+gc_status gc_ctx_destroy(gc_ctx* ctx);
+gc_status gc_ctx_synchronize(gc_ctx* ctx);
+
+/* ------------------------------------------------------------------------ */
+/* Level 1 -- one correlator object per channel, host pointers, synchronous. */
+/* Method-for-method image of Cpu_Multicorrelator_Real_Codes                 */
+/* (cpu_multicorrelator_real_codes.h:48-57).  Pointer arguments are RETAINED, */
+/* not copied, exactly like the reference (cpu_multicorrelator_real_codes.cc: */
+/* 79-98): `shifts_chips` and the code table are re-read on every correlate   */
+/* call, so the caller may edit the shifts between calls.                     */
+/* ------------------------------------------------------------------------ */
+typedef struct gc_correlator gc_correlator;
+gc_status gc_correlator_create(gc_ctx* ctx, gc_correlator** out);
+gc_status gc_correlator_destroy(gc_correlator* c);
+/* ::set_high_dynamics_resampler (.cc:189-193).  The reference constructor
+ * defaults this flag to TRUE (.cc:49); so does gc_correlator_create. */
+gc_status gc_correlator_set_high_dynamics_resampler(gc_correlator* c, int use_high_dynamics_resampler);
+/* ::init (.cc:62-76) */
+gc_status gc_correlator_init(gc_correlator* c, int max_signal_length_samples, int n_correlators);
+/* ::set_local_code_and_taps (.cc:79-89) */
+gc_status gc_correlator_set_local_code_and_taps(gc_correlator* c, int code_length_chips,
+    const float* local_code_in, float* shifts_chips);
+/* ::set_input_output_vectors (.cc:92-98); corr_out: n_correlators complex,
+ * sig_in: >= signal_length_samples complex (host memory) */
+gc_status gc_correlator_set_input_output_vectors(gc_correlator* c, float* corr_out, const float* sig_in);
+/* ::Carrier_wipeoff_multicorrelator_resampler, 7-argument form (.cc:129-152) */
+gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler(gc_correlator* c,
+    float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    int signal_length_samples);
+/* 6-argument form (.cc:155-170): always the plain rotator; the resampler still
+ * follows the high-dynamics flag */
+gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(gc_correlator* c,
+    float rem_carrier_phase_in_rad, float phase_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    int signal_length_samples);
+/* ::free (.cc:173-186) */
+gc_status gc_correlator_free(gc_correlator* c);
+
+/* ------------------------------------------------------------------------ */
+/* Level 2 -- batched tracking engine: all channels of a GPU, many epochs,    */
+/* one launch; IQ, parameters and results resident in HBM.                    */
+/* ------------------------------------------------------------------------ */
+
+/* One channel-epoch of work: the arguments the reference hands to its two
+ * kernels (resampler_32f_xn.h:77 / rotator_dot_prod_32fc_xn.h:81) for one call
+ * of Carrier_wipeoff_multicorrelator_resampler, plus where the window starts. */
+typedef struct
+{
+    uint64_t sample_offset;    /* first IQ sample of the window, relative to the channel's IQ base */
+    float phase0_re, phase0_im;        /* lv_cmake(cos(rem_carr), -sin(rem_carr))   (.cc:141) */
+    float phase_inc_re, phase_inc_im;  /* std::exp(lv_32fc_t(0, -phase_step_rad))   (.cc:149) */
+    float phase_rate_re, phase_rate_im;/* std::exp(lv_32fc_t(0, -phase_rate_step))  (.cc:145); (1,0) = none */
+    float rem_code_phase_chips;        /* in code samples = chips * samples_per_chip */
+    float code_phase_step_chips;
+    float code_phase_rate_step_chips;
+    int32_t n_samples;                 /* integration length (signal_length_samples) */
+} gc_epoch_params; /* 48 bytes */
+
+/* Fills a gc_epoch_params from the reference's scalar arguments with the same
+ * float arithmetic as cpu_multicorrelator_real_codes.cc:141-149 (host libm). */
+void gc_epoch_params_fill(gc_epoch_params* p, uint64_t sample_offset,
+    float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    int signal_length_samples);
+
+typedef struct gc_trk_batch gc_trk_batch;
+/* n_channels channels with n_taps correlator taps each; code tables up to
+ * max_code_length entries.  high_dyn selects the high-dynamics resampler +
+ * rotator pair for every channel of the batch. */
+gc_status gc_trk_batch_create(gc_ctx* ctx, int n_channels, int n_taps, int max_code_length,
+    int high_dyn, gc_trk_batch** out);
+gc_status gc_trk_batch_destroy(gc_trk_batch* b);
+/* Uploads channel `ch`'s code table (float[code_length], +-1 or any real
+ * replica) and tap shifts (float[n_taps], in code samples). (host pointers) */
+gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int code_length,
+    const float* shifts_chips);
+gc_status gc_trk_batch_set_shifts(gc_trk_batch* b, int ch, const float* shifts_chips);
+/* Points channel `ch` at its IQ samples in HBM (n_samples complex).  Channels
+ * of one RF stream may share the same pointer. */
+gc_status gc_trk_batch_set_input_dev(gc_trk_batch* b, int ch, const void* dev_iq, uint64_t n_samples);
+/* Correlates n_epochs epochs of every channel.  dev_params: n_channels*n_epochs
+ * gc_epoch_params, channel-major.  dev_out: n_channels*n_epochs*n_taps complex.
+ * Asynchronous on `stream`. */
+gc_status gc_trk_batch_run_dev(gc_trk_batch* b, int n_epochs, const gc_epoch_params* dev_params,
+    void* dev_out, void* stream);
+/* Same with host parameter/result buffers (copies + synchronises). */
+gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params* host_params,
+    float* host_out);
+/* Engine tuning (no reference counterpart).  Nominal integration length: lets
+ * gc_trk_batch_run_dev pick how many slices to cut an epoch into when the
+ * batch alone would not fill the GPU.  set_slices(0) = automatic. */
+gc_status gc_trk_batch_set_nominal_length(gc_trk_batch* b, int n_samples);
+gc_status gc_trk_batch_set_slices(gc_trk_batch* b, int n_slices);
+
+/* ------------------------------------------------------------------------ */
+/* Acquisition -- PCPS (parallel code phase search), batched over satellites. */
+/* ------------------------------------------------------------------------ */
+
+/* Image of Acq_Conf (src/algorithms/acquisition/libs/acq_conf.h:38-66), the
+ * fields pcps_acquisition reads on this path, plus doppler_step (set through
+ * set_doppler_step in the reference, pcps_acquisition.h:228). */
+typedef struct
+{
+    int64_t fs_in;
+    uint32_t sampled_ms;
+    uint32_t ms_per_code;
+    float samples_per_ms;
+    float samples_per_code;
+    uint32_t samples_per_chip;
+    uint32_t doppler_max;
+    uint32_t doppler_step;
+    uint32_t max_dwells;
+    int32_t bit_transition_flag;
+    int32_t use_CFAR_algorithm_flag;
+    /* engine extension: when > 0 overrides ceil(2*doppler_max/doppler_step)
+     * (pcps_acquisition.cc:326) as the number of Doppler bins */
+    uint32_t num_doppler_bins_override;
+} gc_acq_conf;
+
+/* Per-satellite result of one dwell: what acquisition_core leaves in
+ * Gnss_Synchro / d_test_statistics / d_mag / d_input_power (:747-768). */
+typedef struct
+{
+    uint32_t indext;          /* argmax code-phase index in the grid row */
+    int32_t doppler_hz;       /* -doppler_max + doppler_step*row (:588) */
+    uint32_t doppler_index;
+    float test_statistics;    /* CFAR: max/N^4/input_power; else first/second peak */
+    float mag;                /* raw grid maximum */
+    float input_power;
+    float second_peak;          /* as the reference computes it (the N-byte memcpy at :647) */
+    float second_peak_full_row; /* second peak with the whole peak row considered */
+    double acq_delay_samples; /* fmod((float)indext, samples_per_code) (:766) */
+    double acq_doppler_hz;
+} gc_acq_result;
+
+typedef struct gc_acq gc_acq;
+/* pcps_acquisition ctor + init() for n_sats satellites searched at once. */
+gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq** out);
+gc_status gc_acq_destroy(gc_acq* a);
+gc_status gc_acq_fft_size(const gc_acq* a, uint32_t* fft_size, uint32_t* consumed_samples,
+    uint32_t* num_doppler_bins);
+/* pcps_acquisition::set_local_code for satellite slot `sat` (host pointer to
+ * consumed_samples complex; fft_size/2 with bit_transition_flag). */
+gc_status gc_acq_set_local_code(gc_acq* a, int sat, const float* code);
+/* Clears the magnitude grids and the dwell counter (new search). */
+gc_status gc_acq_reset(gc_acq* a);
+/* One dwell of acquisition_core for every satellite on the same input block
+ * (consumed_samples complex).  Non-coherent accumulation across calls like the
+ * reference (d_num_noncoherent_integrations_counter).  results: n_sats. */
+gc_status gc_acq_dwell_dev(gc_acq* a, const void* dev_iq, gc_acq_result* host_results, void* stream);
+gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_results);
+/* Enqueue-only variant for throughput runs: results stay in HBM until
+ * gc_acq_fetch_results(). */
+gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream);
+gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* stream);
+/* Copies satellite `sat`'s magnitude grid (num_doppler_bins * fft_size floats) to host. */
+gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNSSCORR_H */

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "gnss-sdr-1_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure only)."""
+    from oracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def gctx():
+    """A libgnsscorr context on GPU 0.  Fails (does not skip) when the HIP
+    library or the GPU is missing: GPU tests must exercise the native path."""
+    import gnsscorr
+    ctx = gnsscorr.Context(0)
+    yield ctx
+    ctx.close()

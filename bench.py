@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-acq", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-shared", action="store_true", help="skip the shared-stream extra (clean rocprof runs)")
     args = ap.parse_args()
 
     import torch
@@ -150,13 +151,15 @@ def main():
     E = args.epochs
     n_stream = E * N_EPOCH + 64
     shifts = np.array([-0.5, 0.0, 0.5], np.float32)
-    # channel c of rank r tracks PRN ((r*32 + c) % 32) + 1 on its own IQ buffer
+    # global channel g runs on GPU g mod G; it tracks PRN (g % 32) + 1 on its own IQ buffer
+    from gnsscorr import sharding
+    my_channels = sharding.weak_shard(N_CHANNELS, world, rank)
     streams, params, truths, codes = [], [], [], []
     batch = gnsscorr.TrackingBatch(ctx, N_CHANNELS, N_TAPS, CODE_LEN)
-    for ch in range(N_CHANNELS):
-        prn = (rank * N_CHANNELS + ch) % 32 + 1
+    for ch, gid in enumerate(my_channels):
+        prn = gid % 32 + 1
         code = gps_ca_code(prn)
-        x, truth = make_channel_stream(torch, dev, code, n_stream, seed=1002 + 1000 * rank + ch)
+        x, truth = make_channel_stream(torch, dev, code, n_stream, seed=1002 + 7 * gid)
         streams.append(x)
         truths.append(truth)
         codes.append(code)
@@ -167,7 +170,11 @@ def main():
     h_params = gnsscorr.epoch_params_array(params)
     d_params = torch.from_numpy(h_params.view(np.uint8)).to(dev)
     d_out = torch.zeros(N_CHANNELS * E * N_TAPS, 2, device=dev, dtype=torch.float32)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) HIP stream shared by the launches and the timing events
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     def step():
         batch.run_dev(E, d_params.data_ptr(), d_out.data_ptr(), stream)
@@ -178,6 +185,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()  # inputs were generated on the default stream
     for _ in range(args.warmup):
         step()
     barrier()
@@ -189,16 +197,14 @@ def main():
         ev[i][1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
-        elapsed = float(t.item())
     torch.cuda.synchronize()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     samples_per_step = N_CHANNELS * E * N_EPOCH  # per GPU
-    value = samples_per_step * world * args.steps / elapsed / 1e6
+    value = sharding.aggregate_throughput(samples_per_step, args.steps, world, elapsed) / 1e6
     alg_bytes = 8.0 * samples_per_step
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
@@ -212,20 +218,21 @@ def main():
     if rank == 0:
         extra = {}
         # ---- shared-stream mode: all 32 channels on ONE RF stream (cache-served) ----
-        for ch in range(N_CHANNELS):
-            batch.set_input_dev(ch, streams[0].data_ptr(), n_stream)
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        for _ in range(args.steps):
-            step()
-        s1.record()
-        torch.cuda.synchronize()
-        shared_ms = s0.elapsed_time(s1) / args.steps
-        extra["shared_stream"] = {"value": samples_per_step / (shared_ms * 1e-3) / 1e6, "unit": "Msamples/s",
-            "ms_per_step": shared_ms, "note": "32 channels read one RF stream; input served from L2/Infinity Cache"}
+        if not args.no_shared:
+            for ch in range(N_CHANNELS):
+                batch.set_input_dev(ch, streams[0].data_ptr(), n_stream)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(args.steps):
+                step()
+            s1.record()
+            torch.cuda.synchronize()
+            shared_ms = s0.elapsed_time(s1) / args.steps
+            extra["shared_stream"] = {"value": samples_per_step / (shared_ms * 1e-3) / 1e6, "unit": "Msamples/s",
+                "ms_per_step": shared_ms, "note": "32 channels read one RF stream; input served from L2/Infinity Cache"}
         extra["realtime_factor_256ch"] = value / world / (256 * FS / 1e6)
 
         # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----

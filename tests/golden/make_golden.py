@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures under tests/golden/.
+
+Run in the BUILD container only (needs /root/reference and oracle/_ref, i.e.
+`make -C oracle ref`); the GPU box only ever reads the generated files.
+
+What is produced, and where each expected value comes from:
+
+  ref_resampler.npz   chip indices of volk_gnsssdr_32f_xn_resampler_32f_xn_generic and
+                      ..._high_dynamics_resampler_32f_xn_generic, produced by the REFERENCE's
+                      own kernel headers compiled into oracle/_ref (ramp code trick: code[i] = i).
+  ref_codes.npz       GPS L1 C/A and BeiDou B1I chips / sampled codes from the REFERENCE's
+                      gps_sdr_signal_processing.cc / beidou_b1i_signal_processing.cc (oracle/_ref).
+  ref_sincos.npz      volk_gnsssdr_s32f_sincos_32fc_generic and ..._32f_index_max_32u_generic
+                      outputs (oracle/_ref).
+  galileo_e1_codes.npz  Galileo E1-B / E1-C primary (memory) codes, 50 PRNs x 4092 chips, as +-1
+                      int8: ICD data (Galileo OS SIS ICD, Annex C) read from the hex strings of
+                      src/core/system_parameters/Galileo_E1.h and converted with the bit rule of
+                      hex_to_binary_converter (gnss_signal_processing.cc:58-158: bit 1 -> -1).
+  kat_*.dat           the IQ captures the reference's own acquisition tests read
+                      (src/tests/signal_samples/), data files, copied byte for byte.
+  kat_expected.json   the gates of those tests (gps_l1_ca_pcps_acquisition_test.cc:281-356,
+                      galileo_e1_pcps_ambiguous_acquisition_test.cc:293-358) plus what the
+                      oracle returns on them (oracle-generated values are labelled as such).
+  oracle_epl.npz      E/P/L regression vectors produced by the ORACLE (not by the reference:
+                      the rotator kernel cannot be built here -- "parity unpinned").
+"""
+import json
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+from oracle import Oracle, Ref  # noqa: E402
+from helpers import open_loop_params, synth_stream  # noqa: E402
+
+REF = "/root/reference"
+
+
+def resampler_cases():
+    rng = np.random.Generator(np.random.PCG64(20251004))
+    cases = []
+    # (L, N, samples_per_chip, shifts)
+    shapes = [
+        (1023, 4000, 1, [-0.5, 0.0, 0.5]),
+        (1023, 25000, 1, [-0.5, 0.0, 0.5]),
+        (2046, 25000, 1, [-0.5, 0.0, 0.5]),
+        (8184, 100000, 2, [-1.2, -0.3, 0.0, 0.3, 1.2]),
+        (8184, 16000, 2, [-1.2, -0.3, 0.0, 0.3, 1.2]),
+        (1023, 8111, 1, [0.0]),
+        (1023, 25000, 1, [-0.1, 0.0, 0.1]),
+    ]
+    for L, N, spc, shifts in shapes:
+        for k in range(3):
+            dopp = rng.uniform(-5000, 5000)
+            step = np.float32(L / N * (1.0 + dopp / 1575.42e6))
+            rem = np.float32(rng.uniform(-1.0, 1.0) * step) if k < 2 else np.float32(rng.uniform(-L, L))
+            rate = np.float32(0.0 if k == 0 else rng.uniform(-3e-12, 3e-12))
+            cases.append(dict(L=L, N=N, rem=rem, step=step, shifts=np.array(shifts, np.float32), rate=rate))
+    # multi-period window (index range spans > 2 code periods) and tiny windows
+    cases.append(dict(L=1023, N=10000, rem=np.float32(0.3), step=np.float32(0.25575), shifts=np.array([-0.5, 0, 0.5], np.float32), rate=np.float32(0)))
+    cases.append(dict(L=1023, N=1, rem=np.float32(0.3), step=np.float32(0.25575), shifts=np.array([-0.5, 0, 0.5], np.float32), rate=np.float32(0)))
+    cases.append(dict(L=1023, N=3, rem=np.float32(-2.5), step=np.float32(0.25575), shifts=np.array([-0.5, 0, 0.5], np.float32), rate=np.float32(0)))
+    return cases
+
+
+def main():
+    orc, ref = Oracle(), Ref()
+    out = {}
+    # ---- resampler chip indices from the compiled reference kernels ----
+    cases = resampler_cases()
+    store = {"n_cases": np.int32(len(cases))}
+    for i, c in enumerate(cases):
+        ramp = np.arange(c["L"], dtype=np.float32)
+        idx = ref.resampler(ramp, c["rem"], c["step"], c["shifts"], c["N"]).astype(np.int16)
+        if c["N"] < 16:
+            # the reference's high-dynamics kernel memcpy()s (N - shift_samples) floats with
+            # unsigned arithmetic: it faults when a tap delay exceeds the window, so tiny
+            # windows are pinned for the plain resampler only
+            idx_hd = idx
+            c["rate"] = np.float32(np.nan)
+        else:
+            idx_hd = ref.resampler(ramp, c["rem"], c["step"], c["shifts"], c["N"], rate=c["rate"]).astype(np.int16)
+        # the oracle restatement must agree bit for bit before anything is written
+        assert (orc.resampler_indices(c["rem"], c["step"], c["shifts"], c["L"], c["N"]) == idx).all()
+        if c["N"] >= 16:
+            assert (orc.resampler_indices(c["rem"], c["step"], c["shifts"], c["L"], c["N"], rate=c["rate"]) == idx_hd).all()
+        store["c%d_params" % i] = np.array([c["L"], c["N"]], np.int32)
+        store["c%d_f" % i] = np.array([c["rem"], c["step"], c["rate"]], np.float32)
+        store["c%d_shifts" % i] = c["shifts"]
+        store["c%d_idx" % i] = idx
+        store["c%d_idx_hd" % i] = idx_hd
+    np.savez_compressed(os.path.join(HERE, "ref_resampler.npz"), **store)
+
+    # ---- PRN codes from the compiled reference generators ----
+    codes = {}
+    codes["gps_prn"] = np.array(list(range(1, 33)) + [120, 129, 138], np.int32)
+    codes["gps_chips"] = np.stack([ref.gps_l1_ca_code(int(p)) for p in codes["gps_prn"]]).astype(np.int8)
+    codes["gps_chips_shift7"] = ref.gps_l1_ca_code(5, 7).astype(np.int8)
+    codes["bds_prn"] = np.arange(1, 34, dtype=np.int32)
+    codes["bds_chips"] = np.stack([ref.beidou_b1i_code(int(p)) for p in codes["bds_prn"]]).astype(np.int8)
+    for fs in (4000000, 25000000, 2048000):
+        codes["gps_sampled_fs%d_prn1" % fs] = ref.gps_l1_ca_code_sampled(1, fs).real.astype(np.int8)
+        codes["gps_sampled_fs%d_prn19" % fs] = ref.gps_l1_ca_code_sampled(19, fs).real.astype(np.int8)
+        codes["bds_sampled_fs%d_prn6" % fs] = ref.beidou_b1i_code_sampled(6, fs).real.astype(np.int8)
+    np.savez_compressed(os.path.join(HERE, "ref_codes.npz"), **codes)
+
+    # ---- sincos / index_max from the compiled reference kernels ----
+    sc = {}
+    incs = np.array([-2 * np.pi * 5000 / 25e6, 2 * np.pi * 1680 / 4e6, -0.0031415927, 0.0], np.float32)
+    sc["phase_inc"] = incs
+    for i, inc in enumerate(incs):
+        sc["out%d" % i] = ref.sincos(float(inc), 25000)
+    rng = np.random.Generator(np.random.PCG64(3))
+    v = rng.standard_normal(5000).astype(np.float32)
+    v[[17, 4000]] = v.max() + 1.0  # duplicated maximum: the first one wins
+    sc["imax_in"] = v
+    sc["imax_out"] = np.int64(ref.index_max(v))
+    np.savez_compressed(os.path.join(HERE, "ref_sincos.npz"), **sc)
+
+    # ---- Galileo E1 memory codes (ICD data) ----
+    txt = open(os.path.join(REF, "src/core/system_parameters/Galileo_E1.h")).read()
+    def table(name):
+        m = re.search(name + r"\[GALILEO_E1_NUMBER_OF_CODES\] = \{(.*?)\};", txt, re.S)
+        hexes = re.findall(r'"([0-9A-F]+)"', m.group(1))
+        assert len(hexes) == 50 and all(len(h) == 1023 for h in hexes)
+        arr = np.zeros((50, 4092), np.int8)
+        for p, h in enumerate(hexes):
+            bits = np.array([(int(ch, 16) >> (3 - b)) & 1 for ch in h for b in range(4)], np.int8)
+            arr[p] = 1 - 2 * bits  # hex_to_binary_converter: bit 0 -> +1, bit 1 -> -1
+        return arr
+    e1b, e1c = table("GALILEO_E1_B_PRIMARY_CODE"), table("GALILEO_E1_C_PRIMARY_CODE")
+    np.savez_compressed(os.path.join(HERE, "galileo_e1_codes.npz"), e1b=e1b, e1c=e1c)
+
+    # ---- KAT captures + gates ----
+    shutil.copyfile(os.path.join(REF, "src/tests/signal_samples/GPS_L1_CA_ID_1_Fs_4Msps_2ms.dat"), os.path.join(HERE, "kat_gps_l1_ca_id1_fs4msps_2ms.dat"))
+    shutil.copyfile(os.path.join(REF, "src/tests/signal_samples/Galileo_E1_ID_1_Fs_4Msps_8ms.dat"), os.path.join(HERE, "kat_galileo_e1_id1_fs4msps_8ms.dat"))
+    for f in ("kat_gps_l1_ca_id1_fs4msps_2ms.dat", "kat_galileo_e1_id1_fs4msps_8ms.dat"):
+        os.chmod(os.path.join(HERE, f), 0o644)
+    fs = 4000000
+    kat = {}
+    x = np.fromfile(os.path.join(HERE, "kat_gps_l1_ca_id1_fs4msps_2ms.dat"), np.complex64)
+    p = orc.pcps(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=4000.0,
+        samples_per_chip=4, doppler_max=5000, doppler_step=100)
+    p.set_local_code(orc.gps_l1_ca_code_sampled(1, fs))
+    r = p.core(x)
+    kat["gps_l1_ca"] = dict(file="kat_gps_l1_ca_id1_fs4msps_2ms.dat", fs=fs, prn=1, doppler_max=5000, doppler_step=100,
+        sampled_ms=1, threshold=0.001,
+        reference_test=dict(expected_delay_samples=524, expected_doppler_hz=1680, max_delay_error_chips=0.5, max_doppler_error_hz=666,
+            source="src/tests/unit-tests/signal-processing-blocks/acquisition/gps_l1_ca_pcps_acquisition_test.cc:281-356"),
+        oracle=dict(indext=int(r.indext), doppler=int(r.doppler), test_statistics=float(r.test_statistics), mag=float(r.mag),
+            input_power=float(r.input_power)))
+    x = np.fromfile(os.path.join(HERE, "kat_galileo_e1_id1_fs4msps_8ms.dat"), np.complex64)
+    p = orc.pcps(fs_in=fs, sampled_ms=4, ms_per_code=4, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=16000.0,
+        samples_per_chip=4, doppler_max=10000, doppler_step=250)
+    p.set_local_code(orc.galileo_e1_code_sampled(e1b[0], fs, cboc=False).astype(np.complex64))
+    r = p.core(x)
+    kat["galileo_e1"] = dict(file="kat_galileo_e1_id1_fs4msps_8ms.dat", fs=fs, prn=1, doppler_max=10000, doppler_step=250,
+        sampled_ms=4, threshold=0.0001,
+        reference_test=dict(expected_delay_samples=2920, expected_doppler_hz=-632, max_delay_error_chips=0.175, max_doppler_error_hz=166,
+            source="src/tests/unit-tests/signal-processing-blocks/acquisition/galileo_e1_pcps_ambiguous_acquisition_test.cc:293-358"),
+        oracle=dict(indext=int(r.indext), doppler=int(r.doppler), test_statistics=float(r.test_statistics), mag=float(r.mag),
+            input_power=float(r.input_power)))
+    json.dump(kat, open(os.path.join(HERE, "kat_expected.json"), "w"), indent=1)
+
+    # ---- oracle-generated E/P/L regression vectors (parity unpinned) ----
+    epl = {}
+    cfgs = [("gps_4m", 4000000, 4000, orc.gps_l1_ca_code(1).astype(np.float32), [-0.5, 0, 0.5], 1, 1001),
+            ("gps_25m", 25000000, 25000, orc.gps_l1_ca_code(9).astype(np.float32), [-0.5, 0, 0.5], 1, 1002),
+            ("bds_25m", 25000000, 25000, orc.beidou_b1i_code(6).astype(np.float32), [-0.5, 0, 0.5], 1, 1005),
+            ("gal_25m", 25000000, 100000, orc.galileo_e1_sinboc11(e1b[10]), [-1.2, -0.3, 0, 0.3, 1.2], 2, 1003)]
+    for name, fs, n, code, shifts, spc, seed in cfgs:
+        L = len(code)
+        chip_rate = 1.023e6 * spc * (2 if name.startswith("bds") else 1)
+        sig, truth = synth_stream([code], fs, 3 * n, seed=seed, cn0_db_hz=(44.0, 44.0), chip_rate=chip_rate)
+        shifts = np.array(shifts, np.float32)
+        pr = open_loop_params(truth[0], fs, L, n, 2)
+        outs = []
+        for q in pr:
+            outs.append(orc.multicorrelator(sig[q["sample_offset"]:], code, shifts, q["rem_carr"], q["phase_step"], q["rem_code"], q["code_step"], n))
+        epl[name + "_seed"] = np.int64(seed)
+        epl[name + "_scalars"] = np.array([[q["sample_offset"], q["rem_carr"], q["phase_step"], q["rem_code"], q["code_step"]] for q in pr], np.float64)
+        epl[name + "_out"] = np.array(outs, np.complex64)
+    np.savez_compressed(os.path.join(HERE, "oracle_epl.npz"), **epl)
+    print("golden fixtures written to", HERE)
+    for f in sorted(os.listdir(HERE)):
+        print("  %-44s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+"""CPU tests (no GPU): the oracle against the committed golden vectors.
+
+ref_*.npz come from the REFERENCE's own sources compiled into oracle/_ref
+(tests/golden/make_golden.py); kat_* are the captures and gates of the
+reference's own acquisition tests.  These tests are what "pins" the oracle.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_resampler_chip_indices_match_compiled_reference(oracle):
+    z = np.load(os.path.join(G, "ref_resampler.npz"))
+    n = int(z["n_cases"])
+    assert n >= 20
+    for i in range(n):
+        L, N = (int(v) for v in z["c%d_params" % i])
+        rem, step, rate = (np.float32(v) for v in z["c%d_f" % i])
+        shifts = z["c%d_shifts" % i]
+        got = oracle.resampler_indices(rem, step, shifts, L, N)
+        assert np.array_equal(got, z["c%d_idx" % i].astype(np.int32)), "case %d" % i
+        if not np.isnan(rate):
+            got = oracle.resampler_indices(rem, step, shifts, L, N, rate=rate)
+            assert np.array_equal(got, z["c%d_idx_hd" % i].astype(np.int32)), "hd case %d" % i
+
+
+def test_prn_generators_match_compiled_reference(oracle):
+    z = np.load(os.path.join(G, "ref_codes.npz"))
+    for k, prn in enumerate(z["gps_prn"]):
+        assert np.array_equal(oracle.gps_l1_ca_code(int(prn)), z["gps_chips"][k])
+    assert np.array_equal(oracle.gps_l1_ca_code(5, 7), z["gps_chips_shift7"])
+    for k, prn in enumerate(z["bds_prn"]):
+        assert np.array_equal(oracle.beidou_b1i_code(int(prn)), z["bds_chips"][k])
+    for fs in (4000000, 25000000, 2048000):
+        assert np.array_equal(oracle.gps_l1_ca_code_sampled(1, fs).real, z["gps_sampled_fs%d_prn1" % fs])
+        assert np.array_equal(oracle.gps_l1_ca_code_sampled(19, fs).real, z["gps_sampled_fs%d_prn19" % fs])
+        assert np.array_equal(oracle.beidou_b1i_code_sampled(6, fs).real, z["bds_sampled_fs%d_prn6" % fs])
+
+
+def test_gps_ca_code_properties(oracle):
+    """IS-GPS-200: first 10 chips of PRN 1 are 1100100000 (octal 1440); balanced Gold codes."""
+    c = oracle.gps_l1_ca_code(1)
+    assert "".join("1" if v == 1 else "0" for v in c[:10]) == "1100100000"
+    for prn in range(1, 33):
+        c = oracle.gps_l1_ca_code(prn).astype(np.int64)
+        assert abs(int(c.sum())) == 1
+        ac = np.array([np.dot(c, np.roll(c, k)) for k in (1, 7, 100, 511)])
+        assert set(ac.tolist()) <= {-1, 63, -65}
+
+
+def test_sincos_and_index_max_match_compiled_reference(oracle):
+    z = np.load(os.path.join(G, "ref_sincos.npz"))
+    for i, inc in enumerate(z["phase_inc"]):
+        got = oracle.sincos(float(inc), 25000)
+        assert np.array_equal(got.view(np.float32), z["out%d" % i].view(np.float32))
+    assert oracle.index_max(z["imax_in"]) == int(z["imax_out"]) == 17
+
+
+def test_galileo_e1_codes_and_sinboc(oracle):
+    z = np.load(os.path.join(G, "galileo_e1_codes.npz"))
+    e1b, e1c = z["e1b"], z["e1c"]
+    assert e1b.shape == e1c.shape == (50, 4092)
+    assert set(np.unique(e1b).tolist()) == {-1, 1}
+    # Galileo OS SIS ICD Annex C: E1-B PRN 1 starts with hex F5D710130573..., E1-C PRN 1 with B39340...
+    def first_hex(row, n):
+        bits = (1 - row[:4 * n]) // 2
+        return "".join("%X" % int("".join(str(b) for b in bits[4 * i:4 * i + 4]), 2) for i in range(n))
+    assert first_hex(e1b[0], 12) == "F5D710130573"
+    s = oracle.galileo_e1_sinboc11(e1b[3])
+    assert np.array_equal(s[0::2], e1b[3].astype(np.float32)) and np.array_equal(s[1::2], -e1b[3].astype(np.float32))
+    # sampled replica: 4 Msps -> 16000 samples per 4 ms code, +-1 valued without CBOC
+    c = oracle.galileo_e1_code_sampled(e1b[0], 4000000, cboc=False)
+    assert c.size == 16000 and set(np.unique(c).tolist()) == {-1.0, 1.0}
+    c = oracle.galileo_e1_code_sampled(e1b[0], 4000000, cboc=True)
+    assert c.size == 16000 and len(np.unique(np.abs(c))) == 2
+
+
+def test_fft_matches_numpy(oracle):
+    rng = np.random.Generator(np.random.PCG64(11))
+    for n in (1, 2, 5, 8, 1000, 4000, 2046, 25000):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        f = np.fft.fft(x)
+        assert np.max(np.abs(oracle.fft(x) - f)) <= 1e-12 * max(1.0, np.max(np.abs(f)))
+        assert np.max(np.abs(oracle.fft(x, inverse=True) - np.fft.ifft(x) * n)) <= 1e-12 * max(1.0, np.max(np.abs(f)))
+
+
+def _kat(name):
+    k = json.load(open(os.path.join(G, "kat_expected.json")))[name]
+    x = np.fromfile(os.path.join(G, k["file"]), np.complex64)
+    return k, x
+
+
+def test_pcps_gps_l1_known_answer(oracle):
+    """GpsL1CaPcpsAcquisitionTest.ValidationOfResults gates (reference test :281-356)."""
+    k, x = _kat("gps_l1_ca")
+    fs = k["fs"]
+    p = oracle.pcps(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001),
+        samples_per_code=4000.0, samples_per_chip=4, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+    assert (p.fft_size, p.num_doppler_bins) == (4000, 100)
+    p.set_local_code(oracle.gps_l1_ca_code_sampled(k["prn"], fs))
+    r = p.core(x)
+    g = k["reference_test"]
+    assert abs(r.acq_delay_samples - g["expected_delay_samples"]) * 1023 / 4000 < g["max_delay_error_chips"]
+    assert abs(r.acq_doppler_hz - g["expected_doppler_hz"]) <= g["max_doppler_error_hz"]
+    assert r.test_statistics > k["threshold"]
+    assert (r.indext, r.doppler) == (k["oracle"]["indext"], k["oracle"]["doppler"])
+    assert r.test_statistics == pytest.approx(k["oracle"]["test_statistics"], rel=1e-6)
+
+
+def test_pcps_galileo_e1_known_answer(oracle):
+    """GalileoE1PcpsAmbiguousAcquisitionTest.ValidationOfResults gates (reference test :293-358)."""
+    k, x = _kat("galileo_e1")
+    fs = k["fs"]
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    p = oracle.pcps(fs_in=fs, sampled_ms=4, ms_per_code=4, samples_per_ms=np.float32(fs) * np.float32(0.001),
+        samples_per_code=16000.0, samples_per_chip=4, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+    assert (p.fft_size, p.num_doppler_bins) == (16000, 80)
+    p.set_local_code(oracle.galileo_e1_code_sampled(e1b[k["prn"] - 1], fs, cboc=False).astype(np.complex64))
+    r = p.core(x)
+    g = k["reference_test"]
+    assert abs(r.acq_delay_samples - g["expected_delay_samples"]) * 1023 / 4000 < g["max_delay_error_chips"]
+    assert abs(r.acq_doppler_hz - g["expected_doppler_hz"]) <= g["max_doppler_error_hz"]
+    assert r.test_statistics > k["threshold"]
+
+
+def test_pcps_second_peak_and_dwells(oracle):
+    """Two non-coherent dwells switch the statistic to first/second peak (pcps_acquisition.cc:152-159)
+    and accumulate |.|^2 (:737-738)."""
+    k, x = _kat("gps_l1_ca")
+    fs = k["fs"]
+    p = oracle.pcps(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001),
+        samples_per_code=4000.0, samples_per_chip=4, doppler_max=5000, doppler_step=250, max_dwells=2)
+    assert not p.use_cfar
+    p.set_local_code(oracle.gps_l1_ca_code_sampled(1, fs))
+    r1 = p.core(x[:4000])
+    g1 = p.grid()
+    r2 = p.core(x[4000:])
+    g2 = p.grid()
+    assert np.all(g2 >= g1) and r2.mag > r1.mag
+    assert r1.indext == r2.indext == 524
+    assert r2.second_peak_fixed > 0 and r2.mag / r2.second_peak_fixed > 3.0
+    assert r2.test_statistics == pytest.approx(r2.mag / r2.second_peak)
+
+
+def test_multicorrelator_consistent_with_acquisition_cell(oracle):
+    """Cross-check of the two restatements: |P|^2 of the tracking correlator at the acquisition
+    peak (delay 524, Doppler bin 1700 Hz) equals the PCPS grid cell there (same correlation)."""
+    k, x = _kat("gps_l1_ca")
+    fs, n = k["fs"], 4000
+    p = oracle.pcps(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001),
+        samples_per_code=4000.0, samples_per_chip=4, doppler_max=5000, doppler_step=100)
+    sampled = oracle.gps_l1_ca_code_sampled(1, fs)
+    p.set_local_code(sampled)
+    r = p.core(x)
+    cell = p.grid()[r.doppler_index, r.indext]
+    # correlate the same block with the sampled code delayed by indext and the bin's wipe-off frequency
+    w = p.wipeoffs()[r.doppler_index]
+    ref = np.sum(x[:n].astype(np.complex128) * w[:n] * np.roll(sampled.real, r.indext))
+    # the unnormalised IFFT carries a factor N on the correlation, N^2 on its squared magnitude
+    assert abs(cell - (n * abs(ref)) ** 2) <= 2e-4 * cell
+    # and through the tracking restatement: a 4000-chip table (the sampled code), step 1 chip/sample
+    code = sampled.real.astype(np.float32)
+    out = oracle.multicorrelator(x, code, np.array([0.0], np.float32), np.float32(0.0),
+        np.float32(2 * np.pi * r.doppler / fs), np.float32(r.indext), np.float32(1.0), n)
+    assert abs((n * abs(out[0])) ** 2 - cell) <= 2e-3 * cell
+
+
+def test_oracle_epl_regression(oracle):
+    """The oracle reproduces its own committed E/P/L vectors (guards the restatement against edits)."""
+    import sys
+    from helpers import synth_stream
+    z = np.load(os.path.join(G, "oracle_epl.npz"))
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    cfgs = [("gps_4m", 4000000, 4000, oracle.gps_l1_ca_code(1).astype(np.float32), [-0.5, 0, 0.5], 1.023e6),
+            ("gps_25m", 25000000, 25000, oracle.gps_l1_ca_code(9).astype(np.float32), [-0.5, 0, 0.5], 1.023e6)]
+    for name, fs, n, code, shifts, chip_rate in cfgs:
+        sig, _ = synth_stream([code], fs, 3 * n, seed=int(z[name + "_seed"]), cn0_db_hz=(44.0, 44.0), chip_rate=chip_rate)
+        for row, want in zip(z[name + "_scalars"], z[name + "_out"]):
+            off = int(row[0])
+            got = oracle.multicorrelator(sig[off:], code, np.array(shifts, np.float32), np.float32(row[1]), np.float32(row[2]),
+                np.float32(row[3]), np.float32(row[4]), n)
+            assert np.array_equal(got.view(np.float32), want.view(np.float32))

@@ -1,0 +1,232 @@
+"""GPU parity of the tracking multicorrelator for the other signals / modes of the hot path:
+Galileo E1 (5 taps, 2 samples per chip, 4 ms), BeiDou B1I, the high-dynamics kernels, window
+edge cases, and size-independent properties at BASELINE's full sizes."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import open_loop_params, rel_err, synth_stream
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4
+
+
+def _batch_one(gctx, sig, code, shifts, recs, high_dyn=False, slices=0):
+    import gnsscorr
+    import torch
+    d_sig = torch.from_numpy(np.ascontiguousarray(sig).view(np.float32)).cuda()
+    b = gnsscorr.TrackingBatch(gctx, 1, len(shifts), len(code), high_dyn=high_dyn)
+    b.set_code(0, code, shifts)
+    b.set_input_dev(0, d_sig.data_ptr(), sig.size)
+    if slices:
+        b.set_slices(slices)
+    out = b.run(len(recs), gnsscorr.epoch_params_array(recs))
+    b.close()
+    return out[0]
+
+
+def test_galileo_e1_five_taps_4ms(gctx, oracle):
+    """cfg3 shape: sinBOC(1,1) replica at 2 samples/chip (L = 8184), VE/E/P/L/VL, N = 100000."""
+    import gnsscorr
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    code = oracle.galileo_e1_sinboc11(e1b[10])
+    fs, n = 25_000_000, 100000
+    sig, truth = synth_stream([code], fs, 2 * n + 16, seed=1003, cn0_db_hz=(44.0, 44.0), chip_rate=2 * 1.023e6)
+    shifts = np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32)  # +-0.6, +-0.15 chips x 2 samples/chip
+    recs, refs = [], []
+    for k, p in enumerate(open_loop_params(truth[0], fs, 8184, n, 2)):
+        off = p["sample_offset"] + k * 5
+        recs.append(gnsscorr.epoch_params(off, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n))
+        refs.append(oracle.multicorrelator(sig[off:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n))
+    got = _batch_one(gctx, sig, code, shifts, recs)
+    got_sliced = _batch_one(gctx, sig, code, shifts, recs, slices=9)
+    for k in range(2):
+        assert abs(refs[k][2]) > 0.5 * truth[0]["amp"] * n
+        assert rel_err(got[k], refs[k], 2) <= TOL
+        assert rel_err(got_sliced[k], refs[k], 2) <= TOL
+
+
+def test_beidou_b1i_three_taps(gctx, oracle):
+    import gnsscorr
+    code = oracle.beidou_b1i_code(6).astype(np.float32)
+    fs, n = 25_000_000, 25000
+    sig, truth = synth_stream([code], fs, 3 * n, seed=1005, cn0_db_hz=(44.0, 44.0), chip_rate=2.046e6, carrier_freq=1561.098e6)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    recs, refs = [], []
+    for p in open_loop_params(truth[0], fs, 2046, n, 3):
+        recs.append(gnsscorr.epoch_params(p["sample_offset"], float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n))
+        refs.append(oracle.multicorrelator(sig[p["sample_offset"]:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n))
+    got = _batch_one(gctx, sig, code, shifts, recs)
+    for k in range(3):
+        assert rel_err(got[k], refs[k], 1) <= TOL
+
+
+def test_oracle_epl_golden_vectors(gctx, oracle):
+    """The committed E/P/L fixtures (oracle-generated, tests/golden/oracle_epl.npz)."""
+    import gnsscorr
+    z = np.load(os.path.join(G, "oracle_epl.npz"))
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    cfgs = [("gps_4m", 4000000, 4000, oracle.gps_l1_ca_code(1).astype(np.float32), [-0.5, 0, 0.5], 1.023e6, 1),
+            ("gps_25m", 25000000, 25000, oracle.gps_l1_ca_code(9).astype(np.float32), [-0.5, 0, 0.5], 1.023e6, 1),
+            ("bds_25m", 25000000, 25000, oracle.beidou_b1i_code(6).astype(np.float32), [-0.5, 0, 0.5], 2.046e6, 1),
+            ("gal_25m", 25000000, 100000, oracle.galileo_e1_sinboc11(e1b[10]), [-1.2, -0.3, 0, 0.3, 1.2], 2.046e6, 2)]
+    for name, fs, n, code, shifts, chip_rate, prompt in cfgs:
+        sig, _ = synth_stream([code], fs, 3 * n, seed=int(z[name + "_seed"]), cn0_db_hz=(44.0, 44.0), chip_rate=chip_rate)
+        shifts = np.array(shifts, np.float32)
+        recs = [gnsscorr.epoch_params(int(r[0]), float(np.float32(r[1])), float(np.float32(r[2])), float(np.float32(r[3])),
+            float(np.float32(r[4])), n) for r in z[name + "_scalars"]]
+        got = _batch_one(gctx, sig, code, shifts, recs)
+        for k, want in enumerate(z[name + "_out"]):
+            assert rel_err(got[k], want, prompt) <= TOL, name
+
+
+@pytest.mark.parametrize("n_taps", [1, 2, 4, 8])
+def test_other_tap_counts(gctx, oracle, n_taps):
+    import gnsscorr
+    code = oracle.gps_l1_ca_code(21).astype(np.float32)
+    fs, n = 4_000_000, 4000
+    sig, truth = synth_stream([code], fs, 2 * n, seed=77, cn0_db_hz=(50.0, 50.0))
+    shifts = np.linspace(-0.7, 0.7, n_taps).astype(np.float32) if n_taps > 1 else np.array([0.0], np.float32)
+    p = open_loop_params(truth[0], fs, 1023, n, 1)[0]
+    rec = [gnsscorr.epoch_params(1, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n)]
+    ref = oracle.multicorrelator(sig[1:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
+    got = _batch_one(gctx, sig, code, shifts, rec)[0]
+    assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 63, 511, 512, 513, 1025])
+def test_tiny_and_ragged_windows(gctx, oracle, n):
+    """Empty, single-sample and chunk-boundary windows, odd and even starts."""
+    import gnsscorr
+    code = oracle.gps_l1_ca_code(2).astype(np.float32)
+    rng = np.random.Generator(np.random.PCG64(n + 1))
+    sig = (rng.standard_normal(2048) + 1j * rng.standard_normal(2048)).astype(np.complex64)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    for off in (0, 1, 6, 7):
+        rec = [gnsscorr.epoch_params(off, 0.3, 0.01, -3.25, 0.2557, n)]
+        got = _batch_one(gctx, sig, code, shifts, rec)[0]
+        ref = oracle.multicorrelator(sig[off:], code, shifts, np.float32(0.3), np.float32(0.01), np.float32(-3.25), np.float32(0.2557), n)
+        scale = max(1.0, float(np.sqrt(max(n, 1))))
+        assert np.max(np.abs(got - ref)) <= 1e-5 * scale, (n, off, got, ref)
+
+
+def test_multi_period_window_uses_the_wrapping_path(gctx, oracle):
+    """Index span > LDS window (several code periods per integration): generic modulo path."""
+    import gnsscorr
+    code = oracle.gps_l1_ca_code(30).astype(np.float32)
+    fs, n = 4_000_000, 20000  # 5 code periods
+    sig, truth = synth_stream([code], fs, n + 8, seed=9, cn0_db_hz=(45.0, 45.0))
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    p = open_loop_params(truth[0], fs, 1023, n, 1)[0]
+    rec = [gnsscorr.epoch_params(0, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n)]
+    ref = oracle.multicorrelator(sig, code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
+    got = _batch_one(gctx, sig, code, shifts, rec)[0]
+    assert abs(ref[1]) > 0.5 * truth[0]["amp"] * n
+    assert rel_err(got, ref, 1) <= TOL
+    # negative code step (never produced by the tracking loop, but legal for the kernel)
+    rec = [gnsscorr.epoch_params(0, 0.1, 0.002, 5.5, -0.2557, 4000)]
+    ref = oracle.multicorrelator(sig, code, shifts, np.float32(0.1), np.float32(0.002), np.float32(5.5), np.float32(-0.2557), 4000)
+    got = _batch_one(gctx, sig, code, shifts, rec)[0]
+    assert np.max(np.abs(got - ref)) <= 1e-5 * np.sqrt(4000) + TOL * np.max(np.abs(ref))
+
+
+def test_high_dynamics_resampler_and_rotator(gctx, oracle):
+    """Tracking_XX.high_dyn = true: high-dynamics resampler (tap 0 resampled with the quadratic term,
+    other taps sample-shifted copies) + high-dynamic rotator (carrier phase-rate term)."""
+    import gnsscorr
+    code = oracle.gps_l1_ca_code(14).astype(np.float32)
+    fs, n = 25_000_000, 25000
+    sig, truth = synth_stream([code], fs, 2 * n, seed=31, cn0_db_hz=(46.0, 46.0))
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    p = open_loop_params(truth[0], fs, 1023, n, 1)[0]
+    carr_rate = np.float32(2 * np.pi * 50.0 / fs / fs)  # 50 Hz/s
+    code_rate = np.float32(1e-12)
+    ref = oracle.multicorrelator(sig, code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n,
+        phase_rate_step=carr_rate, code_rate_step=code_rate, high_dyn=True)
+    rec = [gnsscorr.epoch_params(0, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n,
+        carr_phase_rate_step_rad=float(carr_rate), code_phase_rate_step_chips=float(code_rate))]
+    got = _batch_one(gctx, sig, code, shifts, rec, high_dyn=True)[0]
+    assert abs(ref[1]) > 0.5 * truth[0]["amp"] * n
+    assert rel_err(got, ref, 1) <= TOL, (got, ref)
+    # drop-in class: default-constructed object has the high-dynamics flag SET (reference ctor, .cc:49)
+    mc = gnsscorr.HipMulticorrelatorRealCodes(gctx)
+    mc.init(2 * n, 3)
+    out = np.zeros(3, np.complex64)
+    mc.set_local_code_and_taps(1023, code, shifts)
+    mc.set_input_output_vectors(out, sig)
+    mc.Carrier_wipeoff_multicorrelator_resampler(float(p["rem_carr"]), float(p["phase_step"]), float(carr_rate),
+        float(p["rem_code"]), float(p["code_step"]), float(code_rate), n)
+    assert rel_err(out, ref, 1) <= TOL
+    # 6-argument overload: plain rotator, resampler still follows the flag
+    mc.Carrier_wipeoff_multicorrelator_resampler(float(p["rem_carr"]), float(p["phase_step"]),
+        float(p["rem_code"]), float(p["code_step"]), float(code_rate), n)
+    idx = oracle.resampler_indices(p["rem_code"], p["code_step"], shifts, 1023, n, rate=code_rate)
+    wiped = sig[:n].astype(np.complex128) * np.exp(-1j * (float(p["rem_carr"]) + float(p["phase_step"]) * np.arange(n)))
+    want = np.array([np.sum(wiped * code[idx[t]]) for t in range(3)])
+    assert np.max(np.abs(out - want)) <= TOL * abs(want[1])
+    mc.close()
+
+
+def test_shifts_pointer_is_reread_between_calls(gctx, oracle):
+    """The reference keeps the caller's shifts pointer and the tracking block edits it in place when it
+    narrows the correlator spacing (dll_pll_veml_tracking.cc:1753-1764)."""
+    import gnsscorr
+    code = oracle.gps_l1_ca_code(8).astype(np.float32)
+    fs, n = 4_000_000, 4000
+    sig, truth = synth_stream([code], fs, 2 * n, seed=4, cn0_db_hz=(48.0, 48.0))
+    p = open_loop_params(truth[0], fs, 1023, n, 1)[0]
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    mc = gnsscorr.HipMulticorrelatorRealCodes(gctx)
+    mc.set_high_dynamics_resampler(False)
+    mc.init(2 * n, 3)
+    out = np.zeros(3, np.complex64)
+    mc.set_local_code_and_taps(1023, code, shifts)
+    mc.set_input_output_vectors(out, sig)
+    args = (float(p["rem_carr"]), float(p["phase_step"]), 0.0, float(p["rem_code"]), float(p["code_step"]), 0.0, n)
+    mc.Carrier_wipeoff_multicorrelator_resampler(*args)
+    wide = out.copy()
+    shifts[0], shifts[2] = -0.15, 0.15  # edited in place, no setter call
+    mc.Carrier_wipeoff_multicorrelator_resampler(*args)
+    ref = oracle.multicorrelator(sig, code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
+    assert rel_err(out, ref, 1) <= TOL
+    assert abs(out[0]) > abs(wide[0])  # narrower spacing: early/late move up the correlation triangle
+    mc.close()
+
+
+def test_full_size_properties_cfg2(gctx, oracle):
+    """BASELINE configs[1] at full width (32 channels, 25 Msps, 64 epochs, shared stream): properties
+    that need no oracle pass -- linearity in the input, tap symmetry on a noiseless signal, and a
+    spot check of 8 random channel-epochs against the oracle."""
+    import gnsscorr
+    import torch
+    fs, n, n_ch, n_ep = 25_000_000, 25000, 32, 64
+    codes = [oracle.gps_l1_ca_code(prn).astype(np.float32) for prn in range(1, n_ch + 1)]
+    sig, truth = synth_stream(codes, fs, n * n_ep + 8, seed=1002, cn0_db_hz=(40.0, 48.0))
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    d1 = torch.from_numpy(sig.view(np.float32)).cuda()
+    d2 = (d1 * 2.0).contiguous()
+    params = []
+    for ch in range(n_ch):
+        params.append([gnsscorr.epoch_params(p["sample_offset"], float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]),
+            float(p["code_step"]), n) for p in open_loop_params(truth[ch], fs, 1023, n, n_ep)])
+    arr = gnsscorr.epoch_params_array(params)
+    outs = []
+    for d in (d1, d2):
+        b = gnsscorr.TrackingBatch(gctx, n_ch, 3, 1023)
+        for ch in range(n_ch):
+            b.set_code(ch, codes[ch], shifts)
+            b.set_input_dev(ch, d.data_ptr(), sig.size)
+        outs.append(b.run(n_ep, arr))
+        b.close()
+    assert np.array_equal(outs[1], outs[0] * 2)  # scaling by 2 is exact in binary floating point
+    pm = np.abs(outs[0][:, :, 1])
+    for ch in range(n_ch):
+        assert pm[ch].mean() > 0.6 * truth[ch]["amp"] * n
+    rng = np.random.Generator(np.random.PCG64(5))
+    for _ in range(8):
+        ch, k = int(rng.integers(n_ch)), int(rng.integers(n_ep))
+        p = open_loop_params(truth[ch], fs, 1023, n, n_ep)[k]
+        ref = oracle.multicorrelator(sig[p["sample_offset"]:], codes[ch], shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
+        assert rel_err(outs[0][ch, k], ref, 1) <= TOL

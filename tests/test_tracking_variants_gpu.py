@@ -37,7 +37,7 @@ def test_galileo_e1_five_taps_4ms(gctx, oracle):
     shifts = np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32)  # +-0.6, +-0.15 chips x 2 samples/chip
     recs, refs = [], []
     for k, p in enumerate(open_loop_params(truth[0], fs, 8184, n, 2)):
-        off = p["sample_offset"] + k * 5
+        off = p["sample_offset"] + k  # second window starts on an odd sample (0.08 chip off: still on the BOC main peak)
         recs.append(gnsscorr.epoch_params(off, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n))
         refs.append(oracle.multicorrelator(sig[off:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n))
     got = _batch_one(gctx, sig, code, shifts, recs)

@@ -117,6 +117,12 @@ API = {
     "gc_trk_batch_run": (C.c_int, [_vp, C.c_int, _vp, _fp]),
     "gc_trk_batch_set_nominal_length": (C.c_int, [_vp, C.c_int]),
     "gc_trk_batch_set_slices": (C.c_int, [_vp, C.c_int]),
+    "gc_gps_l1_ca_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
+    "gc_gps_l1_ca_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "gc_beidou_b1i_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
+    "gc_beidou_b1i_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "gc_galileo_e1_code_gen_sinboc11_float": (C.c_int, [_fp, C.c_char_p, C.c_uint32]),
+    "gc_galileo_e1_code_gen_complex_sampled": (C.c_int, [_fp, C.c_char_p, C.c_int32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
     "gc_acq_create": (C.c_int, [_vp, C.POINTER(AcqConf), C.c_int, C.POINTER(_vp)]),
     "gc_acq_destroy": (C.c_int, [_vp]),
     "gc_acq_fft_size": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -192,6 +198,47 @@ def epoch_params_array(records):
     for i, p in enumerate(flat):
         out[i] = np.frombuffer(bytes(p), EPOCH_DTYPE)[0]
     return out
+
+
+# ---- PRN replica generators (host side; names follow the reference's free functions) ----
+def gps_l1_ca_code_gen_float(prn, chip_shift=0):
+    d = np.zeros(1023, np.float32)
+    _check(load_library().gc_gps_l1_ca_code_gen_float(_f32p(d), prn, chip_shift))
+    return d
+
+
+def gps_l1_ca_code_gen_complex_sampled(prn, fs, chip_shift=0):
+    d = np.zeros(int(fs // 1000) + 8, np.complex64)
+    n = C.c_int32()
+    _check(load_library().gc_gps_l1_ca_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(_fp), prn, fs, chip_shift, C.byref(n)))
+    return d[:n.value].copy()
+
+
+def beidou_b1i_code_gen_float(prn, chip_shift=0):
+    d = np.zeros(2046, np.float32)
+    _check(load_library().gc_beidou_b1i_code_gen_float(_f32p(d), prn, chip_shift))
+    return d
+
+
+def beidou_b1i_code_gen_complex_sampled(prn, fs, chip_shift=0):
+    d = np.zeros(int(fs // 1000) + 8, np.complex64)
+    n = C.c_int32()
+    _check(load_library().gc_beidou_b1i_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(_fp), prn, fs, chip_shift, C.byref(n)))
+    return d[:n.value].copy()
+
+
+def galileo_e1_code_gen_sinboc11_float(signal, prn):
+    d = np.zeros(8184, np.float32)
+    _check(load_library().gc_galileo_e1_code_gen_sinboc11_float(_f32p(d), signal.encode(), prn))
+    return d
+
+
+def galileo_e1_code_gen_complex_sampled(signal, cboc, prn, fs, chip_shift=0):
+    d = np.zeros(int(fs * 0.004) + 8, np.complex64)
+    n = C.c_int32()
+    _check(load_library().gc_galileo_e1_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(_fp), signal.encode(), int(cboc), prn, fs,
+        chip_shift, C.byref(n)))
+    return d[:n.value].copy()
 
 
 class Context:

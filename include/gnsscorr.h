@@ -154,6 +154,26 @@ gc_status gc_trk_batch_set_nominal_length(gc_trk_batch* b, int n_samples);
 gc_status gc_trk_batch_set_slices(gc_trk_batch* b, int n_slices);
 
 /* ------------------------------------------------------------------------ */
+/* PRN replica generators (host side, set-up path).  Same outputs as the      */
+/* reference's generators; dest buffers are caller-owned host memory.         */
+/* ------------------------------------------------------------------------ */
+/* gps_l1_ca_code_gen_float (src/algorithms/libs/gps_sdr_signal_processing.cc:119-130): 1023 chips, +-1;
+ * PRN 1..32 and SBAS 120..138 */
+gc_status gc_gps_l1_ca_code_gen_float(float* dest, int32_t prn, uint32_t chip_shift);
+/* gps_l1_ca_code_gen_complex_sampled (…:151-196): (int)(fs/1000) complex samples; *n_samples (optional) = count */
+gc_status gc_gps_l1_ca_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift, int32_t* n_samples);
+/* beidou_b1i_code_gen_float / _complex_sampled (src/algorithms/libs/beidou_b1i_signal_processing.cc:115-191): 2046 chips */
+gc_status gc_beidou_b1i_code_gen_float(float* dest, int32_t prn, uint32_t chip_shift);
+gc_status gc_beidou_b1i_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift, int32_t* n_samples);
+/* galileo_e1_code_gen_sinboc11_float (src/algorithms/libs/galileo_e1_signal_processing.cc:108-119): 8184 samples
+ * (2 per chip) of the E1-B ("1B") or E1-C ("1C") primary code, PRN 1..50.  The memory codes are read from
+ * data/galileo_e1_primary_codes.bin next to the library (or $GNSSCORR_GALILEO_E1_CODES). */
+gc_status gc_galileo_e1_code_gen_sinboc11_float(float* dest, const char* signal, uint32_t prn);
+/* galileo_e1_code_gen_complex_sampled (…:232-255) without secondary code: 4 ms of samples at fs */
+gc_status gc_galileo_e1_code_gen_complex_sampled(float* dest, const char* signal, int32_t cboc, uint32_t prn, int32_t fs,
+    uint32_t chip_shift, int32_t* n_samples);
+
+/* ------------------------------------------------------------------------ */
 /* Acquisition -- PCPS (parallel code phase search), batched over satellites. */
 /* ------------------------------------------------------------------------ */
 

@@ -1,0 +1,249 @@
+// adapter_selftest.cpp -- exercises the C++ drop-in layer (Hip_Multicorrelator_Real_Codes,
+// hip_pcps_acquisition, the AcquisitionInterface adapters) the way the reference's own tests
+// drive the corresponding classes:
+//   GpsL1CaPcpsAcquisitionTest.ValidationOfResults
+//     (src/tests/unit-tests/signal-processing-blocks/acquisition/gps_l1_ca_pcps_acquisition_test.cc:276-362)
+//   GalileoE1PcpsAmbiguousAcquisitionTest.ValidationOfResults (…/galileo_e1_pcps_ambiguous_acquisition_test.cc:283-360)
+//   CPU_multicorrelator_real_codes_test (…/tracking/cpu_multicorrelator_real_codes_test.cc:68-171) -- with values asserted.
+// Usage: adapter_selftest <tests/golden directory>.  Needs a GPU (run by pytest -m gpu).
+#include "hip_multicorrelator_real_codes.h"
+#include "pcps_acquisition_adapters.h"
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+static int g_fail = 0;
+#define EXPECT(cond, ...)                                       \
+    do                                                          \
+        {                                                       \
+            if (!(cond))                                        \
+                {                                               \
+                    std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+                    std::printf(__VA_ARGS__);                   \
+                    std::printf("\n");                          \
+                    g_fail++;                                   \
+                }                                               \
+        }                                                       \
+    while (0)
+
+static std::vector<gr_complex> read_iq(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    std::vector<gr_complex> v;
+    if (!f) return v;
+    size_t bytes = static_cast<size_t>(f.tellg());
+    v.resize(bytes / sizeof(gr_complex));
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), bytes);
+    return v;
+}
+
+// feeds a capture to the block in scheduler-sized chunks until it reports an event
+template <class Adapter>
+static void run_flowgraph(Adapter& acq, const std::vector<gr_complex>& x, int chunk)
+{
+    size_t pos = 0;
+    int guard = 0;
+    auto blk = acq.block();
+    while (blk->events().empty() && guard++ < 100000)
+        {
+            int avail = static_cast<int>(std::min<size_t>(chunk, x.size() - pos));
+            if (avail <= 0 && blk->state() != 2) break;  // file source exhausted
+            int used = blk->work(x.data() + pos, avail);
+            pos += used;
+        }
+}
+
+static void test_multicorrelator()
+{
+    // noiseless PRN 1 at 4 Msps, zero Doppler: the reference run recorded in SURVEY.md section 8c gives
+    // E = (2004,0), P = (4000,0), L = (1992,0) for taps -0.5/0/+0.5
+    const int N = 4000;
+    float code[1023];
+    gc_gps_l1_ca_code_gen_float(code, 1, 0);
+    const float step = 1023.0f / 4000.0f;
+    std::vector<std::complex<float>> sig(2 * N);
+    for (int n = 0; n < 2 * N; n++) sig[n] = code[static_cast<int>(std::floor(step * static_cast<float>(n))) % 1023];
+    float shifts[3] = {-0.5f, 0.0f, 0.5f};
+    std::complex<float> out[3];
+    Hip_Multicorrelator_Real_Codes mc;
+    mc.set_high_dynamics_resampler(false);
+    EXPECT(mc.init(2 * N, 3), "init");
+    EXPECT(mc.set_local_code_and_taps(1023, code, shifts), "set_local_code_and_taps");
+    EXPECT(mc.set_input_output_vectors(out, sig.data()), "set_input_output_vectors");
+    EXPECT(mc.Carrier_wipeoff_multicorrelator_resampler(0.0f, 0.0f, 0.0f, 0.0f, step, 0.0f, N), "correlate");
+    EXPECT(mc.last_status() == GC_OK, "status %d: %s", mc.last_status(), gc_last_error());
+    EXPECT(std::abs(out[0] - std::complex<float>(2004, 0)) < 0.01f, "E = (%g,%g)", out[0].real(), out[0].imag());
+    EXPECT(std::abs(out[1] - std::complex<float>(4000, 0)) < 0.01f, "P = (%g,%g)", out[1].real(), out[1].imag());
+    EXPECT(std::abs(out[2] - std::complex<float>(1992, 0)) < 0.01f, "L = (%g,%g)", out[2].real(), out[2].imag());
+    // 6-argument overload, carrier wipe-off of a pure tone: sum(exp(+j w n) * exp(-j w n)) = N
+    for (int n = 0; n < 2 * N; n++) sig[n] *= std::exp(std::complex<float>(0.0f, 0.01f * n + 0.3f));
+    EXPECT(mc.Carrier_wipeoff_multicorrelator_resampler(0.3f, 0.01f, 0.0f, step, 0.0f, N), "correlate6");
+    EXPECT(std::abs(out[1] - std::complex<float>(4000, 0)) < 0.4f, "P6 = (%g,%g)", out[1].real(), out[1].imag());
+    // narrow the spacing in place (dll_pll_veml_tracking.cc:1753-1764): no setter call in between
+    shifts[0] = -0.1f;
+    shifts[2] = 0.1f;
+    EXPECT(mc.Carrier_wipeoff_multicorrelator_resampler(0.3f, 0.01f, 0.0f, step, 0.0f, N), "correlate6b");
+    EXPECT(out[0].real() > 3000.0f && out[2].real() > 3000.0f, "narrow E/L = %g / %g", out[0].real(), out[2].real());
+    EXPECT(mc.free(), "free");
+    std::printf("multicorrelator: E=(%g,%g) P=(%g,%g) L=(%g,%g)\n", out[0].real(), out[0].imag(), out[1].real(), out[1].imag(), out[2].real(), out[2].imag());
+}
+
+struct CountingFsm : public ChannelFsm
+{
+    int valid = 0;
+    bool Event_valid_acquisition() override
+    {
+        valid++;
+        return true;
+    }
+};
+
+static void test_gps_acquisition(const std::string& dir, bool two_steps)
+{
+    auto x = read_iq(dir + "/kat_gps_l1_ca_id1_fs4msps_2ms.dat");
+    EXPECT(x.size() == 8000, "capture size %zu", x.size());
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+    config.set_property("Acquisition_1C.item_type", "gr_complex");
+    config.set_property("Acquisition_1C.coherent_integration_time_ms", "1");
+    config.set_property("Acquisition_1C.threshold", "0.001");
+    config.set_property("Acquisition_1C.doppler_max", "5000");
+    config.set_property("Acquisition_1C.doppler_step", "100");
+    if (two_steps) config.set_property("Acquisition_1C.make_two_steps", "true");
+    Gnss_Synchro gnss_synchro;
+    gnss_synchro.Channel_ID = 0;
+    gnss_synchro.System = 'G';
+    gnss_synchro.Signal[0] = '1';
+    gnss_synchro.Signal[1] = 'C';
+    gnss_synchro.PRN = 1;
+    GpsL1CaPcpsAcquisitionHip acquisition(&config, "Acquisition_1C", 1, 0);
+    EXPECT(acquisition.implementation() == "GPS_L1_CA_PCPS_Acquisition_HIP", "implementation name");
+    acquisition.set_channel(1);
+    acquisition.set_gnss_synchro(&gnss_synchro);
+    acquisition.set_threshold(0.001);
+    acquisition.set_doppler_max(5000);
+    acquisition.set_doppler_step(100);
+    acquisition.init();
+    acquisition.set_local_code();
+    acquisition.set_state(1);
+    run_flowgraph(acquisition, x, 1024);
+    auto blk = acquisition.block();
+    EXPECT(blk->last_status() == GC_OK, "engine status %d: %s", blk->last_status(), gc_last_error());
+    EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "expected message 1 = ACQ SUCCESS (%zu events)", blk->events().size());
+    double delay_error_chips = std::abs(524.0 - gnss_synchro.Acq_delay_samples) * 1023 / 4000;
+    double doppler_error_hz = std::abs(1680.0 - gnss_synchro.Acq_doppler_hz);
+    EXPECT(doppler_error_hz <= (two_steps ? 125.0 : 666.0), "Doppler %g Hz", gnss_synchro.Acq_doppler_hz);
+    EXPECT(delay_error_chips < 0.5, "delay %g samples", gnss_synchro.Acq_delay_samples);
+    if (two_steps) EXPECT(gnss_synchro.Acq_doppler_step == 125, "Acq_doppler_step %u", gnss_synchro.Acq_doppler_step);
+    std::printf("GPS L1 C/A acquisition%s: delay %g samples, Doppler %g Hz, statistic %g, stamp %llu\n", two_steps ? " (two steps)" : "",
+        gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz, blk->test_statistics(), (unsigned long long)gnss_synchro.Acq_samplestamp_samples);
+
+    // negative acquisition: impossible threshold -> message 2, and the direct FSM notification path
+    CountingFsm* raw = new CountingFsm();
+    std::shared_ptr<ChannelFsm> fsm(raw);
+    blk->clear_events();
+    acquisition.set_threshold(1e9f);
+    acquisition.set_state(1);
+    run_flowgraph(acquisition, x, 4000);
+    EXPECT(blk->events().size() == 1 && blk->events()[0] == 2, "expected message 2 = ACQ FAIL");
+    if (!two_steps)
+        {
+            blk->clear_events();
+            acquisition.set_channel_fsm(fsm);
+            acquisition.set_threshold(0.001);
+            acquisition.set_state(1);
+            for (int i = 0; i < 8 && raw->valid == 0; i++) blk->work(x.data(), 4000);
+            EXPECT(raw->valid == 1 && blk->events().empty(), "FSM notified %d times", raw->valid);
+        }
+}
+
+static void test_galileo_acquisition(const std::string& dir)
+{
+    auto x = read_iq(dir + "/kat_galileo_e1_id1_fs4msps_8ms.dat");
+    EXPECT(x.size() == 32000, "capture size %zu", x.size());
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+    config.set_property("Acquisition_1B.coherent_integration_time_ms", "4");
+    config.set_property("Acquisition_1B.doppler_max", "10000");
+    config.set_property("Acquisition_1B.doppler_step", "250");
+    config.set_property("Acquisition_1B.cboc", "true");  // as in the reference test: the adapter reads "Acquisition<ch>.cboc", so this key is inert
+    Gnss_Synchro gnss_synchro;
+    gnss_synchro.System = 'E';
+    gnss_synchro.Signal[0] = '1';
+    gnss_synchro.Signal[1] = 'B';
+    gnss_synchro.PRN = 1;
+    GalileoE1PcpsAmbiguousAcquisitionHip acquisition(&config, "Acquisition_1B", 1, 0);
+    acquisition.set_channel(0);
+    acquisition.set_gnss_synchro(&gnss_synchro);
+    acquisition.set_threshold(0.0001f);
+    acquisition.set_doppler_max(10000);
+    acquisition.set_doppler_step(250);
+    acquisition.init();
+    acquisition.set_local_code();
+    acquisition.set_state(1);
+    run_flowgraph(acquisition, x, 2048);
+    auto blk = acquisition.block();
+    EXPECT(blk->fft_size() == 16000 && blk->num_doppler_bins() == 80, "sizes %u %u", blk->fft_size(), blk->num_doppler_bins());
+    EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "expected ACQ SUCCESS");
+    double delay_error_chips = std::abs(2920.0 - gnss_synchro.Acq_delay_samples) * 1023 / 4000;
+    EXPECT(delay_error_chips < 0.175, "delay %g", gnss_synchro.Acq_delay_samples);
+    EXPECT(std::abs(-632.0 - gnss_synchro.Acq_doppler_hz) <= 166, "Doppler %g", gnss_synchro.Acq_doppler_hz);
+    std::printf("Galileo E1 acquisition: delay %g samples, Doppler %g Hz, statistic %g\n", gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz, blk->test_statistics());
+}
+
+static void test_beidou_sizes()
+{
+    // the BeiDou adapter leaves Acq_Conf::ms_per_code at 0, so the block doubles the FFT (pcps_acquisition.cc:78-85)
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "25000000");
+    Gnss_Synchro gnss_synchro;
+    gnss_synchro.System = 'C';
+    gnss_synchro.Signal[0] = 'B';
+    gnss_synchro.Signal[1] = '1';
+    gnss_synchro.PRN = 6;
+    BeidouB1iPcpsAcquisitionHip acquisition(&config, "Acquisition_B1", 1, 0);
+    acquisition.set_gnss_synchro(&gnss_synchro);
+    acquisition.set_doppler_max(5000);
+    acquisition.set_doppler_step(500);
+    acquisition.set_threshold(0.01f);
+    acquisition.init();
+    acquisition.set_local_code();
+    auto blk = acquisition.block();
+    EXPECT(blk->consumed_samples() == 25000 && blk->fft_size() == 50000, "BeiDou sizes %u %u", blk->consumed_samples(), blk->fft_size());
+    EXPECT(blk->last_status() == GC_OK, "engine status %d: %s", blk->last_status(), gc_last_error());
+    // a delayed, Doppler-shifted replica of the local code is found where it was put
+    std::vector<gr_complex> code(25008), x(25000);
+    gc_beidou_b1i_code_gen_complex_sampled(reinterpret_cast<float*>(code.data()), 6, 25000000, 0, nullptr);
+    const int delay = 7777;
+    for (int n = 0; n < 25000; n++) x[n] = code[(n - delay + 25000) % 25000] * std::exp(gr_complex(0.0f, 2.0f * 3.14159265f * 1500.0f * n / 25e6f));
+    acquisition.set_state(1);
+    run_flowgraph(acquisition, x, 25000);
+    EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "BeiDou ACQ SUCCESS");
+    EXPECT(std::abs(gnss_synchro.Acq_delay_samples - delay) <= 1.0 && gnss_synchro.Acq_doppler_hz == 1500.0, "BeiDou delay %g Doppler %g",
+        gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz);
+    std::printf("BeiDou B1I acquisition: delay %g samples, Doppler %g Hz\n", gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2)
+        {
+            std::printf("usage: %s <golden dir>\n", argv[0]);
+            return 2;
+        }
+    if (gc_device_count() == 0)
+        {
+            std::printf("no GPU: libgnsscorr has no CPU fallback\n");
+            return 3;
+        }
+    test_multicorrelator();
+    test_gps_acquisition(argv[1], false);
+    test_gps_acquisition(argv[1], true);
+    test_galileo_acquisition(argv[1]);
+    test_beidou_sizes();
+    std::printf(g_fail ? "%d FAILURES\n" : "adapter self-test passed\n", g_fail);
+    return g_fail ? 1 : 0;
+}

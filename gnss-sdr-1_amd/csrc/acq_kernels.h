@@ -80,6 +80,9 @@ struct AcqFinalArgs
     int use_cfar;
     int samples_per_chip;
     float samples_per_code;
+    int step_two;       // Doppler of a row follows the step-two formula (pcps_acquisition.cc:589-591)
+    float center_step_two, doppler_step2;
+    int n_bins_step2;
 };
 hipError_t acq_launch_final(hipStream_t st, const AcqFinalArgs& a, int n_sats);
 

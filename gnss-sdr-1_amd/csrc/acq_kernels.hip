@@ -520,7 +520,10 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_final_kernel(AcqFinalArgs a)
     gc_acq_result r;
     r.indext = tim;
     r.doppler_index = row;
-    r.doppler_hz = -a.doppler_max + a.doppler_step * (int)row;
+    if (!a.step_two)
+        r.doppler_hz = -a.doppler_max + a.doppler_step * (int)row;
+    else
+        r.doppler_hz = (int)(a.center_step_two + ((float)row - (float)floor(a.n_bins_step2 / 2.0)) * a.doppler_step2);
     r.mag = peak;
     r.input_power = a.input_power ? *a.input_power : 0.0f;
     r.second_peak = 0.0f;

@@ -15,7 +15,12 @@ struct gc_acq
     gc_ctx* ctx = nullptr;
     gc_acq_conf conf{};
     int n_sats = 0;
-    uint32_t fft_size = 0, consumed = 0, eff = 0, n_bins = 0;
+    uint32_t fft_size = 0, consumed = 0, eff = 0, n_bins = 0;  // n_bins: bins of the ACTIVE grid
+    uint32_t n_bins_main = 0, n_bins_alloc = 0;
+    bool step_two = false;
+    float center_step_two = 0.0f;
+    float2* d_wipe_main = nullptr;
+    float2* d_wipe2 = nullptr;
     bool use_cfar = false;
     uint32_t max_dwells = 1;
     uint32_t dwell_counter = 0;
@@ -44,7 +49,8 @@ static void acq_release(gc_acq* a)
 {
     (void)hipFree(a->d_wN);
     (void)hipFree(a->d_wN2);
-    (void)hipFree(a->d_wipe);
+    (void)hipFree(a->d_wipe_main);
+    (void)hipFree(a->d_wipe2);
     (void)hipFree(a->d_codes);
     (void)hipFree(a->d_xw);
     (void)hipFree(a->d_X);
@@ -79,7 +85,7 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     GC_REQUIRE(ctx && conf && out, "gc_acq_create: NULL argument");
     *out = nullptr;
     GC_REQUIRE(n_sats > 0, "gc_acq_create: n_sats must be > 0");
-    GC_REQUIRE(conf->sampled_ms > 0 && conf->ms_per_code > 0 && conf->samples_per_ms > 0.0f, "gc_acq_create: bad sizes");
+    GC_REQUIRE(conf->sampled_ms > 0 && conf->samples_per_ms > 0.0f, "gc_acq_create: bad sizes");
     GC_REQUIRE(conf->doppler_step > 0, "gc_acq_create: doppler_step must be > 0");
     gc_device_guard g(ctx->device);
     gc_acq* a = new gc_acq();
@@ -102,6 +108,9 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     // :326
     a->n_bins = (uint32_t)std::ceil((double)((int32_t)conf->doppler_max - (int32_t)(-(int32_t)conf->doppler_max)) / (double)conf->doppler_step);
     if (conf->num_doppler_bins_override > 0) a->n_bins = conf->num_doppler_bins_override;
+    a->n_bins_main = a->n_bins;
+    a->n_bins_alloc = a->n_bins;
+    if (conf->make_2_steps && conf->num_doppler_bins_step2 > a->n_bins_alloc) a->n_bins_alloc = conf->num_doppler_bins_step2;
     if (a->n_bins == 0 || a->fft_size == 0)
         {
             delete a;
@@ -116,24 +125,26 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     const size_t N = a->fft_size;
     a->n_blocks = acq_cols_blocks(a->plan);
     // scratch Q: keep a batch of satellites within ~96 MB so that it lives in the Infinity Cache
-    size_t per_sat = (size_t)a->n_bins * N * sizeof(float2);
+    size_t per_sat = (size_t)a->n_bins_alloc * N * sizeof(float2);
     a->sats_per_batch = (int)((96u << 20) / per_sat);
     if (a->sats_per_batch < 1) a->sats_per_batch = 1;
     if (a->sats_per_batch > n_sats) a->sats_per_batch = n_sats;
-    size_t q_cells = (size_t)a->sats_per_batch * a->n_bins;
-    if (q_cells < a->n_bins) q_cells = a->n_bins;
+    size_t q_cells = (size_t)a->sats_per_batch * a->n_bins_alloc;
 
     ACQ_TRY(hipMalloc(&a->d_wN, N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_wN2, (size_t)a->plan.N2 * sizeof(float2)));
-    ACQ_TRY(hipMalloc(&a->d_wipe, (size_t)a->n_bins * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_wipe_main, (size_t)a->n_bins_main * N * sizeof(float2)));
+    a->d_wipe = a->d_wipe_main;
+    if (conf->make_2_steps && conf->num_doppler_bins_step2 > 0)
+        ACQ_TRY(hipMalloc(&a->d_wipe2, (size_t)conf->num_doppler_bins_step2 * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_codes, (size_t)n_sats * N * sizeof(float2)));
-    ACQ_TRY(hipMalloc(&a->d_xw, (size_t)a->n_bins * N * sizeof(float2)));
-    ACQ_TRY(hipMalloc(&a->d_X, (size_t)a->n_bins * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_xw, (size_t)a->n_bins_alloc * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_X, (size_t)a->n_bins_alloc * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_Q, q_cells * N * sizeof(float2)));
-    ACQ_TRY(hipMalloc(&a->d_grid, (size_t)n_sats * a->n_bins * N * sizeof(float)));
+    ACQ_TRY(hipMalloc(&a->d_grid, (size_t)n_sats * a->n_bins_alloc * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_tmp, (size_t)n_sats * N * sizeof(float)));
-    ACQ_TRY(hipMalloc(&a->d_blkv, (size_t)n_sats * a->n_bins * a->n_blocks * sizeof(float)));
-    ACQ_TRY(hipMalloc(&a->d_blki, (size_t)n_sats * a->n_bins * a->n_blocks * sizeof(unsigned)));
+    ACQ_TRY(hipMalloc(&a->d_blkv, (size_t)n_sats * a->n_bins_alloc * a->n_blocks * sizeof(float)));
+    ACQ_TRY(hipMalloc(&a->d_blki, (size_t)n_sats * a->n_bins_alloc * a->n_blocks * sizeof(unsigned)));
     ACQ_TRY(hipMalloc(&a->d_power, sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_in, N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_results, (size_t)n_sats * sizeof(gc_acq_result)));
@@ -176,7 +187,7 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
         (void)hipFree(d_inc);
         ACQ_TRY(e);
     }
-    ACQ_TRY(hipMemsetAsync(a->d_grid, 0, (size_t)n_sats * a->n_bins * N * sizeof(float), st));
+    ACQ_TRY(hipMemsetAsync(a->d_grid, 0, (size_t)n_sats * a->n_bins_alloc * N * sizeof(float), st));
     ACQ_TRY(hipMemsetAsync(a->d_tmp, 0, (size_t)n_sats * N * sizeof(float), st));
     ACQ_TRY(hipMemsetAsync(a->d_codes, 0, (size_t)n_sats * N * sizeof(float2), st));
     ACQ_TRY(hipMemsetAsync(a->d_power, 0, sizeof(float), st));
@@ -241,8 +252,48 @@ gc_status gc_acq_reset(gc_acq* a)
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
     // grid reset (:917-924) and d_num_noncoherent_integrations_counter = 0
-    GC_HIP(hipMemsetAsync(a->d_grid, 0, (size_t)a->n_sats * a->n_bins * a->fft_size * sizeof(float), a->ctx->stream));
+    GC_HIP(hipMemsetAsync(a->d_grid, 0, (size_t)a->n_sats * a->n_bins_alloc * a->fft_size * sizeof(float), a->ctx->stream));
     a->dwell_counter = 0;
+    return GC_OK;
+}
+
+gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz)
+{
+    GC_REQUIRE(a, "gc_acq_set_step_two: NULL handle");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = a->ctx->stream;
+    if (!enable)
+        {
+            a->step_two = false;
+            a->n_bins = a->n_bins_main;
+            a->d_wipe = a->d_wipe_main;
+            a->dwell_counter = 0;
+            return GC_OK;
+        }
+    if (!a->conf.make_2_steps || !a->d_wipe2) return gc_fail(GC_ERR_STATE, "gc_acq_set_step_two: the plan was created without make_2_steps");
+    const uint32_t n2 = a->conf.num_doppler_bins_step2;
+    // update_grid_doppler_wipeoffs_step2 (pcps_acquisition.cc:383-390) + update_local_carrier (:296-310)
+    std::vector<float> inc(n2);
+    for (uint32_t d = 0; d < n2; d++)
+        {
+            float doppler = (static_cast<float>(d) - static_cast<float>(std::floor(n2 / 2.0))) * a->conf.doppler_step2;
+            float freq = doppler_center_hz + doppler;
+            float phase_step_rad = (float)(6.283185307179586 * freq / (float)a->conf.fs_in);
+            inc[d] = -phase_step_rad;
+        }
+    float* d_inc = nullptr;
+    GC_HIP(hipMalloc(&d_inc, sizeof(float) * n2));
+    hipError_t e = hipMemcpy(d_inc, inc.data(), sizeof(float) * n2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe2, (int)n2, (int)a->fft_size);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_inc);
+    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_step_two: %s", hipGetErrorString(e));
+    a->step_two = true;
+    a->center_step_two = doppler_center_hz;
+    a->n_bins = n2;
+    a->d_wipe = a->d_wipe2;
+    a->dwell_counter = 0;  // d_num_noncoherent_integrations_counter = 0 (:848)
     return GC_OK;
 }
 
@@ -299,6 +350,10 @@ static gc_status acq_enqueue(gc_acq* a, const float2* dev_iq, hipStream_t st)
             f.use_cfar = a->use_cfar ? 1 : 0;
             f.samples_per_chip = (int)a->conf.samples_per_chip;
             f.samples_per_code = a->conf.samples_per_code;
+            f.step_two = a->step_two ? 1 : 0;
+            f.center_step_two = a->center_step_two;
+            f.doppler_step2 = a->conf.doppler_step2;
+            f.n_bins_step2 = (int)a->conf.num_doppler_bins_step2;
             e = acq_launch_final(st, f, a->n_sats);
         }
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: kernel launch failed: %s", hipGetErrorString(e));

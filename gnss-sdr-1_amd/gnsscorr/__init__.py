@@ -69,6 +69,9 @@ class AcqConf(C.Structure):
         ("bit_transition_flag", C.c_int32),
         ("use_CFAR_algorithm_flag", C.c_int32),
         ("num_doppler_bins_override", C.c_uint32),
+        ("make_2_steps", C.c_int32),
+        ("num_doppler_bins_step2", C.c_uint32),
+        ("doppler_step2", C.c_float),
     ]
 
 
@@ -128,6 +131,7 @@ API = {
     "gc_acq_fft_size": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gc_acq_set_local_code": (C.c_int, [_vp, C.c_int, _fp]),
     "gc_acq_reset": (C.c_int, [_vp]),
+    "gc_acq_set_step_two": (C.c_int, [_vp, C.c_int, C.c_float]),
     "gc_acq_dwell_dev": (C.c_int, [_vp, _vp, C.POINTER(AcqResult), _vp]),
     "gc_acq_dwell": (C.c_int, [_vp, _fp, C.POINTER(AcqResult)]),
     "gc_acq_dwell_enqueue": (C.c_int, [_vp, _vp, _vp]),
@@ -389,11 +393,13 @@ class PcpsAcquisition:
     search the same input block."""
 
     def __init__(self, ctx, n_sats, fs_in, sampled_ms, ms_per_code, samples_per_ms, samples_per_code, samples_per_chip,
-            doppler_max, doppler_step, max_dwells=1, bit_transition_flag=False, use_cfar=True, num_doppler_bins_override=0):
+            doppler_max, doppler_step, max_dwells=1, bit_transition_flag=False, use_cfar=True, num_doppler_bins_override=0,
+            make_2_steps=False, num_doppler_bins_step2=4, doppler_step2=125.0):
         self._ctx = ctx
         self.n_sats = n_sats
         conf = AcqConf(int(fs_in), sampled_ms, ms_per_code, samples_per_ms, samples_per_code, samples_per_chip,
-            doppler_max, doppler_step, max_dwells, int(bit_transition_flag), int(use_cfar), num_doppler_bins_override)
+            doppler_max, doppler_step, max_dwells, int(bit_transition_flag), int(use_cfar), num_doppler_bins_override,
+            int(make_2_steps), num_doppler_bins_step2, doppler_step2)
         self.conf = conf
         self._h = _vp()
         _check(load_library().gc_acq_create(ctx._h, C.byref(conf), n_sats, C.byref(self._h)))
@@ -409,6 +415,12 @@ class PcpsAcquisition:
 
     def reset(self):
         _check(load_library().gc_acq_reset(self._h))
+
+    def set_step_two(self, enable, doppler_center_hz=0.0):
+        _check(load_library().gc_acq_set_step_two(self._h, int(enable), float(doppler_center_hz)))
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(load_library().gc_acq_fft_size(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.num_doppler_bins = c.value
 
     def dwell(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)

@@ -196,6 +196,11 @@ typedef struct
     /* engine extension: when > 0 overrides ceil(2*doppler_max/doppler_step)
      * (pcps_acquisition.cc:326) as the number of Doppler bins */
     uint32_t num_doppler_bins_override;
+    /* two-step acquisition (Acq_Conf::make_2_steps, num_doppler_bins_step2, doppler_step2;
+     * defaults 4 bins of 125 Hz, gps_l1_ca_pcps_acquisition.cc:86-88) */
+    int32_t make_2_steps;
+    uint32_t num_doppler_bins_step2;
+    float doppler_step2;
 } gc_acq_conf;
 
 /* Per-satellite result of one dwell: what acquisition_core leaves in
@@ -225,6 +230,11 @@ gc_status gc_acq_fft_size(const gc_acq* a, uint32_t* fft_size, uint32_t* consume
 gc_status gc_acq_set_local_code(gc_acq* a, int sat, const float* code);
 /* Clears the magnitude grids and the dwell counter (new search). */
 gc_status gc_acq_reset(gc_acq* a);
+/* Second step of make_2_steps (pcps_acquisition.cc:771-829, 957-963): enable != 0 switches the search to
+ * num_doppler_bins_step2 bins of doppler_step2 Hz centred on doppler_center_hz
+ * (update_grid_doppler_wipeoffs_step2, :383-390) and restarts the dwell counter; enable == 0 returns to
+ * the coarse grid.  Results then follow the step-two Doppler formula (:589-591). */
+gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz);
 /* One dwell of acquisition_core for every satellite on the same input block
  * (consumed_samples complex).  Non-coherent accumulation across calls like the
  * reference (d_num_noncoherent_integrations_counter).  results: n_sats. */

@@ -20,7 +20,7 @@ def _declared_symbols():
 
 def test_header_compiles_as_c_and_cpp(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "gnsscorr.h"\nint main(void){ return (sizeof(gc_epoch_params) == 48 && sizeof(gc_acq_conf) == 56 && sizeof(gc_acq_result) == 48) ? 0 : 1; }\n')
+    src.write_text('#include "gnsscorr.h"\nint main(void){ return (sizeof(gc_epoch_params) == 48 && sizeof(gc_acq_conf) == 64 && sizeof(gc_acq_result) == 48) ? 0 : 1; }\n')
     for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
         exe = str(tmp_path / ("t_" + cc))
         f = str(src) if cc == "gcc" else str(tmp_path / "t.cpp")
@@ -48,7 +48,7 @@ def test_struct_layouts():
     assert gnsscorr.EpochParams.sample_offset.offset == 0
     assert gnsscorr.EpochParams.n_samples.offset == 44
     assert C.sizeof(gnsscorr.AcqResult) == 48
-    assert C.sizeof(gnsscorr.AcqConf) == 56
+    assert C.sizeof(gnsscorr.AcqConf) == 64
 
 
 def test_epoch_params_fill_follows_reference_arithmetic():

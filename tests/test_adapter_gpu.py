@@ -1,0 +1,53 @@
+"""GPU test of the C++ drop-in layer (gnss-sdr-1_amd/adapter/): Hip_Multicorrelator_Real_Codes,
+hip_pcps_acquisition and the AcquisitionInterface adapters, driven the way the reference's own
+GoogleTests drive the classes they mirror (adapter_selftest.cpp)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_adapter_selftest():
+    exe = os.path.join(ROOT, "gnss-sdr-1_amd", "adapter", "adapter_selftest")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    env = dict(os.environ)
+    # the C++ program links /opt/rocm's HIP runtime itself (no torch in that process)
+    p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300, env=env)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "adapter self-test passed" in p.stdout
+
+
+def test_two_step_acquisition_matches_reference_formulas(gctx, oracle):
+    """make_two_steps: second pass over second_nbins bins of second_doppler_step Hz centred on the coarse
+    Doppler (pcps_acquisition.cc:383-390), Doppler reported with the step-two formula (:589-591)."""
+    import json
+    import gnsscorr
+    G = os.path.join(ROOT, "tests", "golden")
+    k = json.load(open(os.path.join(G, "kat_expected.json")))["gps_l1_ca"]
+    x = np.fromfile(os.path.join(G, k["file"]), np.complex64)
+    fs = k["fs"]
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, fs, 1, 1, np.float32(fs) * np.float32(0.001), 4000.0, 4, 5000, 250,
+        make_2_steps=True, num_doppler_bins_step2=4, doppler_step2=125.0)
+    acq.set_local_code(0, oracle.gps_l1_ca_code_sampled(1, fs))
+    r1 = acq.dwell(x)[0]
+    assert acq.num_doppler_bins == 40 and r1.doppler_hz == 1750
+    acq.set_step_two(True, float(r1.acq_doppler_hz))
+    assert acq.num_doppler_bins == 4
+    r2 = acq.dwell(x)[0]
+    # bins: 1750 + (d - 2) * 125 = 1500, 1625, 1750, 1875 -> the capture's 1680 Hz lands in 1625 or 1750
+    assert r2.indext == 524 and r2.doppler_hz in (1625, 1750)
+    assert r2.doppler_hz == int(1750.0 + (r2.doppler_index - 2) * 125.0)
+    # same wipe-off frequencies through the oracle's float32 running-phase table
+    w = oracle.sincos(-np.float32(2 * np.pi * np.float32(r2.doppler_hz) / np.float32(fs)), 4000)
+    sampled = oracle.gps_l1_ca_code_sampled(1, fs).real
+    ref = np.sum(x[:4000].astype(np.complex128) * w * np.roll(sampled, 524))
+    assert r2.mag == pytest.approx((4000 * abs(ref)) ** 2, rel=2e-4)
+    acq.set_step_two(False)
+    assert acq.num_doppler_bins == 40
+    acq.close()

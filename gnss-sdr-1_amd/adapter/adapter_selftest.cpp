@@ -41,16 +41,18 @@ static std::vector<gr_complex> read_iq(const std::string& path)
 }
 
 // feeds a capture to the block in scheduler-sized chunks until it reports an event
+// (repeat = file_source's repeat flag: the 2 ms capture is too short for a two-step search)
 template <class Adapter>
-static void run_flowgraph(Adapter& acq, const std::vector<gr_complex>& x, int chunk)
+static void run_flowgraph(Adapter& acq, const std::vector<gr_complex>& x, int chunk, bool repeat = false)
 {
     size_t pos = 0;
     int guard = 0;
     auto blk = acq.block();
     while (blk->events().empty() && guard++ < 100000)
         {
+            if (repeat && pos >= x.size()) pos = 0;
             int avail = static_cast<int>(std::min<size_t>(chunk, x.size() - pos));
-            if (avail <= 0 && blk->state() != 2) break;  // file source exhausted
+            if (avail <= 0) break;  // file source exhausted: the scheduler stops calling general_work
             int used = blk->work(x.data() + pos, avail);
             pos += used;
         }
@@ -88,7 +90,7 @@ static void test_multicorrelator()
     EXPECT(mc.Carrier_wipeoff_multicorrelator_resampler(0.3f, 0.01f, 0.0f, step, 0.0f, N), "correlate6b");
     EXPECT(out[0].real() > 3000.0f && out[2].real() > 3000.0f, "narrow E/L = %g / %g", out[0].real(), out[2].real());
     EXPECT(mc.free(), "free");
-    std::printf("multicorrelator: E=(%g,%g) P=(%g,%g) L=(%g,%g)\n", out[0].real(), out[0].imag(), out[1].real(), out[1].imag(), out[2].real(), out[2].imag());
+    std::printf("multicorrelator: noiseless E/P/L = 2004/4000/1992 reproduced; narrow spacing E=(%g,%g) P=(%g,%g) L=(%g,%g)\n", out[0].real(), out[0].imag(), out[1].real(), out[1].imag(), out[2].real(), out[2].imag());
 }
 
 struct CountingFsm : public ChannelFsm
@@ -129,7 +131,7 @@ static void test_gps_acquisition(const std::string& dir, bool two_steps)
     acquisition.init();
     acquisition.set_local_code();
     acquisition.set_state(1);
-    run_flowgraph(acquisition, x, 1024);
+    run_flowgraph(acquisition, x, 1024, two_steps);
     auto blk = acquisition.block();
     EXPECT(blk->last_status() == GC_OK, "engine status %d: %s", blk->last_status(), gc_last_error());
     EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "expected message 1 = ACQ SUCCESS (%zu events)", blk->events().size());
@@ -215,12 +217,12 @@ static void test_beidou_sizes()
     EXPECT(blk->consumed_samples() == 25000 && blk->fft_size() == 50000, "BeiDou sizes %u %u", blk->consumed_samples(), blk->fft_size());
     EXPECT(blk->last_status() == GC_OK, "engine status %d: %s", blk->last_status(), gc_last_error());
     // a delayed, Doppler-shifted replica of the local code is found where it was put
-    std::vector<gr_complex> code(25008), x(25000);
+    std::vector<gr_complex> code(25008), x(30000);  // a few samples past the dwell: the block needs one more call to leave state 1
     gc_beidou_b1i_code_gen_complex_sampled(reinterpret_cast<float*>(code.data()), 6, 25000000, 0, nullptr);
     const int delay = 7777;
-    for (int n = 0; n < 25000; n++) x[n] = code[(n - delay + 25000) % 25000] * std::exp(gr_complex(0.0f, 2.0f * 3.14159265f * 1500.0f * n / 25e6f));
+    for (int n = 0; n < 30000; n++) x[n] = code[(n - delay + 25000) % 25000] * std::exp(gr_complex(0.0f, 2.0f * 3.14159265f * 1500.0f * n / 25e6f));
     acquisition.set_state(1);
-    run_flowgraph(acquisition, x, 25000);
+    run_flowgraph(acquisition, x, 5000);
     EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "BeiDou ACQ SUCCESS");
     EXPECT(std::abs(gnss_synchro.Acq_delay_samples - delay) <= 1.0 && gnss_synchro.Acq_doppler_hz == 1500.0, "BeiDou delay %g Doppler %g",
         gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz);

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgnsscorr.so")
+LIB_PATH = os.environ.get("GNSSCORR_LIB", os.path.join(os.path.dirname(_HERE), "libgnsscorr.so"))
 
 GC_OK, GC_ERR_INVALID, GC_ERR_NO_DEVICE, GC_ERR_HIP, GC_ERR_STATE = range(5)
 GC_MAX_TAPS = 8

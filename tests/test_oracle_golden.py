@@ -184,3 +184,15 @@ def test_oracle_epl_regression(oracle):
             got = oracle.multicorrelator(sig[off:], code, np.array(shifts, np.float32), np.float32(row[1]), np.float32(row[2]),
                 np.float32(row[3]), np.float32(row[4]), n)
             assert np.array_equal(got.view(np.float32), want.view(np.float32))
+
+
+def test_survey_probe_of_the_genuine_reference(oracle):
+    """SURVEY.md section 8c records a run of the REFERENCE's own Cpu_Multicorrelator_Real_Codes (compiled
+    during the survey): a noiseless PRN-1 input at 4 Msps, 3 taps at -0.5/0/+0.5 chips, N = 4000 gave
+    P = (4000,0), E = (2004,0), L = (1992,0).  The oracle's rotator + accumulate restatement reproduces it."""
+    code = oracle.gps_l1_ca_code(1).astype(np.float32)
+    step = np.float32(1023.0 / 4000)
+    idx = oracle.resampler_indices(np.float32(0), step, np.array([0], np.float32), 1023, 4000)[0]
+    sig = code[idx].astype(np.complex64)
+    out = oracle.multicorrelator(sig, code, np.array([-0.5, 0, 0.5], np.float32), np.float32(0), np.float32(0), np.float32(0), step, 4000)
+    assert out.tolist() == [2004 + 0j, 4000 + 0j, 1992 + 0j]

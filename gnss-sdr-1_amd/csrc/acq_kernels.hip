@@ -476,45 +476,76 @@ __global__ __launch_bounds__(1024) void acq_input_power_kernel(const float2* __r
 }
 
 // ---- final statistics, one workgroup per satellite ----
-__global__ __launch_bounds__(ACQ_THREADS) void acq_final_kernel(AcqFinalArgs a)
+#define ACQ_FINAL_THREADS 1024
+struct MaxKey
+{
+    float v;
+    unsigned long long k;  // row * N + index: orders equal values like the reference's scan
+};
+static __device__ __forceinline__ MaxKey max_key(MaxKey a, MaxKey b)
+{
+    return (b.v > a.v || (b.v == a.v && b.k < a.k)) ? b : a;
+}
+
+__global__ __launch_bounds__(ACQ_FINAL_THREADS) void acq_final_kernel(AcqFinalArgs a)
 {
     const int sat = blockIdx.x;
     const int N = a.fft_size;
+    const int tid = threadIdx.x;
     __shared__ float s_peak;
     __shared__ unsigned s_row, s_time;
-    __shared__ float sv[ACQ_THREADS / 64];
-    __shared__ unsigned si[ACQ_THREADS / 64];
-    if (threadIdx.x == 0)
-        {
-            // rows in increasing Doppler, strict '>' (pcps_acquisition.cc:575-585 / :611-621)
-            float peak = 0.0f;
-            unsigned row = 0, tim = 0;
-            for (int d = 0; d < a.n_bins; d++)
-                {
-                    const size_t cell = (size_t)sat * a.n_bins + d;
-                    MaxPair b = {a.blk_max_val[cell * a.n_blocks], a.blk_max_idx[cell * a.n_blocks]};
-                    for (int k = 1; k < a.n_blocks; k++)
-                        {
-                            MaxPair c = {a.blk_max_val[cell * a.n_blocks + k], a.blk_max_idx[cell * a.n_blocks + k]};
-                            b = max_pair(b, c);
-                        }
-                    if (b.i == 0xffffffffu)
-                        {
-                            b.i = 0;
-                            b.v = a.grid[cell * N];
-                        }
-                    if (b.v > peak)
-                        {
-                            peak = b.v;
-                            row = (unsigned)d;
-                            tim = b.i;
-                        }
-                }
-            s_peak = peak;
-            s_row = row;
-            s_time = tim;
-        }
-    __syncthreads();
+    __shared__ float sv[ACQ_FINAL_THREADS / 64];
+    __shared__ unsigned long long sk[ACQ_FINAL_THREADS / 64];
+    __shared__ unsigned si[ACQ_FINAL_THREADS / 64];
+    {
+        // Global maximum over the per-block row maxima.  The reference scans rows in increasing Doppler
+        // with a strict '>' on the row maxima (pcps_acquisition.cc:575-585 / :611-621), each row maximum
+        // being the FIRST maximum of its row: the winner is the largest value, ties going to the
+        // smallest (row, index).
+        MaxKey b = {-1.0f, ~0ull};
+        const int total = a.n_bins * a.n_blocks;
+        for (int i = tid; i < total; i += ACQ_FINAL_THREADS)
+            {
+                const int d = i / a.n_blocks;
+                const size_t e = ((size_t)sat * a.n_bins + d) * a.n_blocks + (i % a.n_blocks);
+                const unsigned idx = a.blk_max_idx[e];
+                if (idx == 0xffffffffu) continue;  // block without kept samples
+                MaxKey c = {a.blk_max_val[e], (unsigned long long)d * (unsigned long long)N + idx};
+                b = max_key(b, c);
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            {
+                MaxKey o;
+                o.v = __shfl_down(b.v, off, 64);
+                o.k = __shfl_down(b.k, off, 64);
+                b = max_key(b, o);
+            }
+        if ((tid & 63) == 0)
+            {
+                sv[tid >> 6] = b.v;
+                sk[tid >> 6] = b.k;
+            }
+        __syncthreads();
+        if (tid == 0)
+            {
+                for (int w = 1; w < ACQ_FINAL_THREADS / 64; w++)
+                    {
+                        MaxKey c = {sv[w], sk[w]};
+                        b = max_key(b, c);
+                    }
+                // grid_maximum starts at 0.0 with a strict '>': an all-zero grid keeps row 0 / index 0
+                if (!(b.v > 0.0f))
+                    {
+                        b.v = 0.0f;
+                        b.k = 0;
+                    }
+                s_peak = b.v;
+                s_row = (unsigned)(b.k / (unsigned long long)N);
+                s_time = (unsigned)(b.k % (unsigned long long)N);
+            }
+        __syncthreads();
+    }
     const float peak = s_peak;
     const unsigned row = s_row, tim = s_time;
     gc_acq_result r;
@@ -545,22 +576,21 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_final_kernel(AcqFinalArgs a)
                 e1 = N + e1;
             else if (e2 >= N)
                 e2 = e2 - N;
+            int len = e2 - e1;  // the do-while clears e1, e1+1, ... (circular) up to but excluding e2
+            if (len <= 0) len += N;
             const float* grow = a.grid + ((size_t)sat * a.n_bins + row) * N;
             float* tmp = a.tmp + (size_t)sat * N;
             // memcpy(d_tmp_buffer, row, d_fft_size) copies d_fft_size BYTES = N/4 floats (:647)
             const int n_copied = N / 4;
-            // excluded indices: e1, e1+1, ... (circular) up to but excluding e2; the loop is a
-            // do-while, so e1 is always cleared
             MaxPair best_bug = {-1.0f, 0xffffffffu}, best_full = {-1.0f, 0xffffffffu};
-            for (int i = threadIdx.x; i < N; i += ACQ_THREADS)
+            for (int i = tid; i < N; i += ACQ_FINAL_THREADS)
                 {
                     int d = i - e1;
                     if (d < 0) d += N;
-                    int len = e2 - e1;
-                    if (len <= 0) len += N;
                     const bool excluded = d < len;
-                    float vb = (i < n_copied) ? grow[i] : tmp[i];
-                    float vf = grow[i];
+                    const float g = grow[i];
+                    float vb = (i < n_copied) ? g : tmp[i];
+                    float vf = g;
                     if (excluded)
                         {
                             vb = 0.0f;
@@ -583,14 +613,14 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_final_kernel(AcqFinalArgs a)
                             b = max_pair(b, o);
                         }
                     __syncthreads();
-                    if ((threadIdx.x & 63) == 0)
+                    if ((tid & 63) == 0)
                         {
-                            sv[threadIdx.x >> 6] = b.v;
-                            si[threadIdx.x >> 6] = b.i;
+                            sv[tid >> 6] = b.v;
+                            si[tid >> 6] = b.i;
                         }
                     __syncthreads();
                     MaxPair t = {sv[0], si[0]};
-                    for (int w = 1; w < ACQ_THREADS / 64; w++)
+                    for (int w = 1; w < ACQ_FINAL_THREADS / 64; w++)
                         {
                             MaxPair c = {sv[w], si[w]};
                             t = max_pair(t, c);
@@ -605,7 +635,7 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_final_kernel(AcqFinalArgs a)
     // :764-768
     r.acq_delay_samples = (double)fmodf((float)tim, a.samples_per_code);
     r.acq_doppler_hz = (double)r.doppler_hz;
-    if (threadIdx.x == 0) a.results[sat] = r;
+    if (tid == 0) a.results[sat] = r;
 }
 
 // -----------------------------------------------------------------------------
@@ -795,6 +825,6 @@ hipError_t acq_launch_input_power(hipStream_t st, const float2* x, int n_valid, 
 
 hipError_t acq_launch_final(hipStream_t st, const AcqFinalArgs& a, int n_sats)
 {
-    hipLaunchKernelGGL(acq_final_kernel, dim3(n_sats), dim3(ACQ_THREADS), 0, st, a);
+    hipLaunchKernelGGL(acq_final_kernel, dim3(n_sats), dim3(ACQ_FINAL_THREADS), 0, st, a);
     return hipGetLastError();
 }

@@ -13,6 +13,7 @@ struct AcqFftPlan
     int N, N1, N2;
     int n_fac;
     int fac[ACQ_MAX_FACTORS];  // radices of the N2-point row FFT, product = N2
+    int tw_off[ACQ_MAX_FACTORS];  // offset of each stage's twiddle table inside the stage-twiddle array
     float2 w1[ACQ_MAX_N1];     // exp(-2*pi*j*k/N1), k < N1
 };
 
@@ -45,6 +46,9 @@ struct AcqMagArgs
 
 bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes);
 size_t acq_rows_lds_bytes(const AcqFftPlan& plan);
+// per-stage twiddles of the N2-point row FFT: stage f at out[tw_off[f] + (k-1)*m + q] = exp(-2*pi*j*q*k/n_f)
+// (N2 - 1 entries in total), followed by the plain table exp(-2*pi*j*i/N2), i < N2 (generic radices)
+void acq_stage_twiddles(const AcqFftPlan& plan, float2* out /* 2*N2 entries */);
 
 // out[a*N2 + b] = in[a + N1*b] (* mul[a + N1*b]); in is zero beyond n_valid
 hipError_t acq_launch_permute(hipStream_t st, const float2* in, const float2* mul, float2* out,

@@ -123,14 +123,19 @@ static __device__ __forceinline__ void dftR(float2* a)
 // ---- one Stockham stage of the LDS row FFT ----
 // current length n = R*m, stride s (product of the radices already done), N2 = n*s.
 //   y[r + s*(R*q + k)] = w_n^(q*k) * sum_j x[r + s*(q + m*j)] * w_R^(j*k)
+// twf: this stage's twiddles in global memory laid out [k-1][q] (unit stride across lanes; the
+// table is a few KB shared by every workgroup, so it lives in L1/L2 and costs no LDS)
 template <int R, bool INV>
 static __device__ __forceinline__ void lds_stage(const float2* __restrict__ x, float2* __restrict__ y,
-    const float2* __restrict__ tw, int N2, int m, int s)
+    const float2* __restrict__ twf, int N2, int m, int s)
 {
     const int nb = N2 / R;
     for (int u = threadIdx.x; u < nb; u += ACQ_THREADS)
         {
             const int r = u % s, q = u / s;
+            float2 w[R];
+#pragma unroll
+            for (int k = 1; k < R; k++) w[k] = twf[(k - 1) * m + q];
             float2 a[R];
 #pragma unroll
             for (int j = 0; j < R; j++) a[j] = x[r + s * (q + m * j)];
@@ -138,18 +143,14 @@ static __device__ __forceinline__ void lds_stage(const float2* __restrict__ x, f
             const int base = r + s * R * q;
             y[base] = a[0];
 #pragma unroll
-            for (int k = 1; k < R; k++)
-                {
-                    float2 w = tw[q * k * s];  // w_n^(q*k) = w_N2^(q*k*s)
-                    y[base + s * k] = INV ? cmul_conj(a[k], w) : cmul(a[k], w);
-                }
+            for (int k = 1; k < R; k++) y[base + s * k] = INV ? cmul_conj(a[k], w[k]) : cmul(a[k], w[k]);
         }
 }
 
-// generic (prime) radix: O(R^2) butterfly with table twiddles
+// generic (prime) radix: O(R^2) butterfly; twp = plain table exp(-2*pi*j*i/N2) in global memory
 template <bool INV>
 static __device__ void lds_stage_generic(const float2* __restrict__ x, float2* __restrict__ y,
-    const float2* __restrict__ tw, int N2, int R, int m, int s)
+    const float2* __restrict__ twp, int N2, int R, int m, int s)
 {
     const int nb = N2 / R;
     const int wR = N2 / R;  // w_R^e = w_N2^(e*N2/R)
@@ -162,11 +163,11 @@ static __device__ void lds_stage_generic(const float2* __restrict__ x, float2* _
                     for (int j = 0; j < R; j++)
                         {
                             float2 v = x[r + s * (q + m * j)];
-                            float2 w = tw[((j * k) % R) * wR];
+                            float2 w = twp[((j * k) % R) * wR];
                             float2 p = INV ? cmul_conj(v, w) : cmul(v, w);
                             acc = cadd(acc, p);
                         }
-                    float2 w = tw[q * k * s];
+                    float2 w = twp[q * k * s];
                     y[r + s * (R * q + k)] = INV ? cmul_conj(acc, w) : cmul(acc, w);
                 }
         }
@@ -182,12 +183,11 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
     const int N2 = plan.N2, N = plan.N;
     float2* buf0 = sm;
     float2* buf1 = sm + N2;
-    float2* tw = sm + 2 * N2;
+    const float2* twp = wN2 + N2;  // plain table behind the per-stage tables
     const int k1 = blockIdx.x;
     const int cell = blockIdx.y;
     const size_t row = (size_t)k1 * N2;
     const float2* a = A + (size_t)((cell / mapA.div) % mapA.mod) * N + row;
-    for (int i = threadIdx.x; i < N2; i += ACQ_THREADS) tw[i] = wN2[i];
     if (B)
         {
             const float2* bb = B + (size_t)((cell / mapB.div) % mapB.mod) * N + row;
@@ -205,14 +205,15 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
         {
             const int R = plan.fac[f];
             const int m = n / R;
+            const float2* twf = wN2 + plan.tw_off[f];
             switch (R)
                 {
-                case 2: lds_stage<2, INV>(src, dst, tw, N2, m, s); break;
-                case 3: lds_stage<3, INV>(src, dst, tw, N2, m, s); break;
-                case 4: lds_stage<4, INV>(src, dst, tw, N2, m, s); break;
-                case 5: lds_stage<5, INV>(src, dst, tw, N2, m, s); break;
-                case 8: lds_stage<8, INV>(src, dst, tw, N2, m, s); break;
-                default: lds_stage_generic<INV>(src, dst, tw, N2, R, m, s); break;
+                case 2: lds_stage<2, INV>(src, dst, twf, N2, m, s); break;
+                case 3: lds_stage<3, INV>(src, dst, twf, N2, m, s); break;
+                case 4: lds_stage<4, INV>(src, dst, twf, N2, m, s); break;
+                case 5: lds_stage<5, INV>(src, dst, twf, N2, m, s); break;
+                case 8: lds_stage<8, INV>(src, dst, twf, N2, m, s); break;
+                default: lds_stage_generic<INV>(src, dst, twp, N2, R, m, s); break;
                 }
             __syncthreads();
             float2* t = src;
@@ -221,14 +222,16 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
             n = m;
             s *= R;
         }
-    // leave LDS through the inter-pass twiddle w_N^(k1*n2)
+    // leave LDS through the inter-pass twiddle w_N^(k1*n2); the table is stored as the matrix
+    // T[k1][n2] so that a row reads it with unit stride
     float2* q = Q + (size_t)cell * N + row;
+    const float2* wrow = wN + row;
     for (int i = threadIdx.x; i < N2; i += ACQ_THREADS)
         {
             float2 v = src[i];
             if (k1 > 0)
                 {
-                    float2 w = wN[(size_t)k1 * i];
+                    float2 w = wrow[i];
                     v = INV ? cmul_conj(v, w) : cmul(v, w);
                 }
             q[i] = v;
@@ -671,7 +674,29 @@ static bool factor_rows(int N2, int* fac, int* n_fac)
     return true;
 }
 
-size_t acq_rows_lds_bytes(const AcqFftPlan& plan) { return (size_t)3 * plan.N2 * sizeof(float2); }
+size_t acq_rows_lds_bytes(const AcqFftPlan& plan) { return (size_t)2 * plan.N2 * sizeof(float2); }
+
+void acq_stage_twiddles(const AcqFftPlan& plan, float2* out)
+{
+    int n = plan.N2;
+    for (int f = 0; f < plan.n_fac; f++)
+        {
+            const int R = plan.fac[f], m = n / R;
+            for (int k = 1; k < R; k++)
+                for (int q = 0; q < m; q++)
+                    {
+                        double ang = -2.0 * M_PI * (double)q * (double)k / (double)n;
+                        out[plan.tw_off[f] + (k - 1) * m + q] = make_float2((float)cos(ang), (float)sin(ang));
+                    }
+            n = m;
+        }
+    out[plan.N2 - 1] = make_float2(1.f, 0.f);
+    for (int i = 0; i < plan.N2; i++)
+        {
+            double ang = -2.0 * M_PI * (double)i / (double)plan.N2;
+            out[plan.N2 + i] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+}
 
 bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes)
 {
@@ -686,7 +711,7 @@ bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes)
         {
             if (N % n1) continue;
             int n2 = N / n1;
-            if ((size_t)3 * n2 * sizeof(float2) > lds_limit_bytes) continue;
+            if ((size_t)2 * n2 * sizeof(float2) > lds_limit_bytes) continue;
             int fac[ACQ_MAX_FACTORS], nf;
             if (!factor_rows(n2, fac, &nf)) continue;
             long cost = labs((long)n2 - 1024);
@@ -701,6 +726,17 @@ bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes)
     plan->N1 = best;
     plan->N2 = N / best;
     factor_rows(plan->N2, plan->fac, &plan->n_fac);
+    {
+        // offsets of the per-stage twiddle tables [k-1][q] (sizes sum to N2 - 1)
+        int n = plan->N2, off = 0;
+        for (int f = 0; f < plan->n_fac; f++)
+            {
+                const int R = plan->fac[f], m = n / R;
+                plan->tw_off[f] = off;
+                off += (R - 1) * m;
+                n = m;
+            }
+    }
     for (int k = 0; k < best; k++)
         {
             double a = -2.0 * M_PI * (double)k / (double)best;

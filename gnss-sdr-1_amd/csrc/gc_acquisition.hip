@@ -132,7 +132,7 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     size_t q_cells = (size_t)a->sats_per_batch * a->n_bins_alloc;
 
     ACQ_TRY(hipMalloc(&a->d_wN, N * sizeof(float2)));
-    ACQ_TRY(hipMalloc(&a->d_wN2, (size_t)a->plan.N2 * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_wN2, (size_t)2 * a->plan.N2 * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_wipe_main, (size_t)a->n_bins_main * N * sizeof(float2)));
     a->d_wipe = a->d_wipe_main;
     if (conf->make_2_steps && conf->num_doppler_bins_step2 > 0)
@@ -155,19 +155,18 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     // twiddle tables, rounded from float64
     {
         std::vector<float2> w(N);
-        for (size_t k = 0; k < N; k++)
-            {
-                double ang = -2.0 * M_PI * (double)k / (double)N;
-                w[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-            }
+        // inter-pass twiddles as the matrix T[k1][n2] = exp(-2*pi*j*k1*n2/N): unit-stride reads per row
+        for (size_t k1 = 0; k1 < (size_t)a->plan.N1; k1++)
+            for (size_t n2 = 0; n2 < (size_t)a->plan.N2; n2++)
+                {
+                    double ang = -2.0 * M_PI * (double)((k1 * n2) % N) / (double)N;
+                    w[k1 * a->plan.N2 + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+                }
         ACQ_TRY(hipMemcpy(a->d_wN, w.data(), N * sizeof(float2), hipMemcpyHostToDevice));
-        const size_t N2 = a->plan.N2;
-        for (size_t k = 0; k < N2; k++)
-            {
-                double ang = -2.0 * M_PI * (double)k / (double)N2;
-                w[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-            }
-        ACQ_TRY(hipMemcpy(a->d_wN2, w.data(), N2 * sizeof(float2), hipMemcpyHostToDevice));
+        // row-FFT twiddles: per-stage tables + plain table (acq_stage_twiddles)
+        std::vector<float2> w2((size_t)2 * a->plan.N2);
+        acq_stage_twiddles(a->plan, w2.data());
+        ACQ_TRY(hipMemcpy(a->d_wN2, w2.data(), w2.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
     // Doppler wipe-off grid: init() (:340-357) + update_local_carrier (:296-310)
     {

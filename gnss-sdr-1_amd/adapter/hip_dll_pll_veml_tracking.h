@@ -1,0 +1,442 @@
+/*!
+ * \file hip_dll_pll_veml_tracking.h
+ * \brief Image of the dll_pll_veml_tracking block
+ * (src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.{h,cc}) for the three signals of the
+ * hot path (GPS L1 C/A "1C", Galileo E1 "1B", BeiDou B1I "B1"), with the correlations done by
+ * Hip_Multicorrelator_Real_Codes (libgnsscorr.so, MI355X).
+ *
+ * Mirrored: constructor set-up of taps/shifts (dll_pll_veml_tracking.cc:330-440), start_tracking (:549-747),
+ * the state machine of general_work for states 0 (standby), 1 (pull-in) and 2 (wide tracking) (:1544-1773),
+ * do_correlation_step (:886-911), run_dll_pll (:914-973), update_tracking_vars (:998-1070) incl. the
+ * high-dynamics rate smoother, cn0_and_tracking_lock_status (:839-878), the Gnss_Synchro record written
+ * per epoch (:1730-1770, :1898-1906).
+ * Not mirrored (outside the correlator hot path): telemetry preamble / secondary-code synchronisation and
+ * the extended-integration states 3/4 that it enables (the block stays in state 2), binary dumps,
+ * the telemetry fault message handler, the pilot (E1-C) component.
+ *
+ * general_work(noutput, ninput_items, input_items, output_items) becomes
+ * work(in, ninput_items, out): returns the number of input items consumed (consume_each) and sets
+ * *produced to 1 when *out was written; "events" messages (3 = loss of lock) are queued in events().
+ */
+#ifndef GNSSCORR_HIP_DLL_PLL_VEML_TRACKING_H_
+#define GNSSCORR_HIP_DLL_PLL_VEML_TRACKING_H_
+
+#include "gnss_sdr_types.h"
+#include "hip_multicorrelator_real_codes.h"
+#include "tracking_loop_maths.h"
+#include <cmath>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+class hip_dll_pll_veml_tracking
+{
+public:
+    explicit hip_dll_pll_veml_tracking(const Dll_Pll_Conf& conf_) : trk_parameters(conf_)
+    {
+        signal_type = std::string(trk_parameters.signal);
+        d_symbols_per_bit = 1;
+        if (trk_parameters.system == 'G' && signal_type == "1C")
+            {
+                d_signal_carrier_freq = 1575.42e6;  // GPS_L1_FREQ_HZ
+                d_code_period = 0.001;
+                d_code_chip_rate = 1.023e6;
+                d_correlation_length_ms = 1;
+                d_code_samples_per_chip = 1;
+                d_code_length_chips = 1023;
+                trk_parameters.track_pilot = false;
+            }
+        else if (trk_parameters.system == 'E' && signal_type == "1B")
+            {
+                d_signal_carrier_freq = 1575.42e6;  // Galileo_E1_FREQ_HZ
+                d_code_period = 0.004;
+                d_code_chip_rate = 1.023e6;
+                d_code_length_chips = 4092;
+                d_correlation_length_ms = 4;
+                d_code_samples_per_chip = 2;  // sinBOC(1,1) replica, 2 samples per chip
+                d_veml = true;
+                trk_parameters.track_pilot = false;  // E1-C pilot tracking is not mirrored
+            }
+        else if (trk_parameters.system == 'C' && signal_type == "B1")
+            {
+                d_signal_carrier_freq = 1.561098e9;  // BEIDOU_B1I_FREQ_HZ
+                d_code_period = 0.001;
+                d_code_chip_rate = 2.046e6;
+                d_code_length_chips = 2046;
+                d_correlation_length_ms = 1;
+                d_code_samples_per_chip = 1;
+                trk_parameters.track_pilot = false;
+            }
+        d_code_loop_filter = Tracking_loop_filter(d_code_period, trk_parameters.dll_bw_hz, trk_parameters.dll_filter_order, false);
+        d_carrier_loop_filter.set_params(trk_parameters.fll_bw_hz, trk_parameters.pll_bw_hz, trk_parameters.pll_filter_order);
+        d_tracking_code.assign(2 * d_code_length_chips, 0.0f);
+        d_n_correlator_taps = d_veml ? 5 : 3;
+        d_correlator_outs.assign(d_n_correlator_taps, gr_complex(0.0, 0.0));
+        d_local_code_shift_chips.assign(d_n_correlator_taps, 0.0f);
+        set_tap_shifts();
+        multicorrelator_cpu.init(2 * trk_parameters.vector_length, d_n_correlator_taps);
+        multicorrelator_cpu.set_high_dynamics_resampler(trk_parameters.high_dyn);
+        d_code_freq_chips = d_code_chip_rate;
+        d_current_prn_length_samples = static_cast<int32_t>(trk_parameters.vector_length);
+        d_Prompt_buffer.assign(trk_parameters.cn0_samples, gr_complex(0.0, 0.0));
+        d_carrier_lock_threshold = trk_parameters.carrier_lock_th;
+        d_carr_ph_history_cap = 2 * trk_parameters.smoother_length;
+    }
+
+    void set_channel(uint32_t channel) { d_channel = channel; }
+    void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) { d_acquisition_gnss_synchro = p_gnss_synchro; }
+
+    //! dll_pll_veml_tracking::start_tracking (:549-747)
+    void start_tracking()
+    {
+        std::lock_guard<std::mutex> l(d_setlock);
+        d_acq_code_phase_samples = d_acquisition_gnss_synchro->Acq_delay_samples;
+        d_acq_carrier_doppler_hz = d_acquisition_gnss_synchro->Acq_doppler_hz;
+        d_acq_sample_stamp = d_acquisition_gnss_synchro->Acq_samplestamp_samples;
+        d_carrier_doppler_hz = d_acq_carrier_doppler_hz;
+        d_carrier_phase_step_rad = PI_2 * d_carrier_doppler_hz / trk_parameters.fs_in;
+        d_carrier_phase_rate_step_rad = 0.0;
+        d_carr_ph_history.clear();
+        d_code_ph_history.clear();
+        d_carrier_loop_filter.initialize(static_cast<float>(d_acq_carrier_doppler_hz));
+        d_code_loop_filter.initialize();
+        if (trk_parameters.system == 'G')
+            gc_gps_l1_ca_code_gen_float(d_tracking_code.data(), static_cast<int32_t>(d_acquisition_gnss_synchro->PRN), 0);
+        else if (trk_parameters.system == 'E')
+            {
+                char sig[3] = "1B";
+                gc_galileo_e1_code_gen_sinboc11_float(d_tracking_code.data(), sig, d_acquisition_gnss_synchro->PRN);
+            }
+        else
+            gc_beidou_b1i_code_gen_float(d_tracking_code.data(), static_cast<int32_t>(d_acquisition_gnss_synchro->PRN), 0);
+        multicorrelator_cpu.set_local_code_and_taps(d_code_samples_per_chip * d_code_length_chips, d_tracking_code.data(), d_local_code_shift_chips.data());
+        std::fill(d_correlator_outs.begin(), d_correlator_outs.end(), gr_complex(0.0, 0.0));
+        d_carrier_lock_fail_counter = 0;
+        d_rem_code_phase_samples = 0.0;
+        d_rem_carr_phase_rad = 0.0;
+        d_rem_code_phase_chips = 0.0;
+        d_acc_carrier_phase_rad = 0.0;
+        d_cn0_estimation_counter = 0;
+        d_carrier_lock_test = 1.0;
+        d_CN0_SNV_dB_Hz = 0.0;
+        set_tap_shifts();
+        d_current_correlation_time_s = d_code_period;
+        d_code_loop_filter.set_noise_bandwidth(trk_parameters.dll_bw_hz);
+        d_code_loop_filter.set_update_interval(d_code_period);
+        d_state = 1;  // pull-in
+        d_cloop = true;
+        d_pull_in_transitory = true;
+    }
+
+    void stop_tracking()
+    {
+        std::lock_guard<std::mutex> l(d_setlock);
+        d_state = 0;
+    }
+
+    //! forecast (:507-514): the scheduler calls work() with at least this many items
+    int required_input_items() const { return static_cast<int>(trk_parameters.vector_length) * 2; }
+
+    /*! general_work (:1544-1907), states 0..2 */
+    int work(const gr_complex* in, int ninput_items, Gnss_Synchro* out, int* produced)
+    {
+        std::lock_guard<std::mutex> l(d_setlock);
+        *produced = 0;
+        Gnss_Synchro current_synchro_data = Gnss_Synchro();
+        if (d_pull_in_transitory == true)
+            {
+                if (trk_parameters.pull_in_time_s < (d_sample_counter - d_acq_sample_stamp) / static_cast<int>(trk_parameters.fs_in)) d_pull_in_transitory = false;
+            }
+        switch (d_state)
+            {
+            case 0:  // standby
+                d_sample_counter += static_cast<uint64_t>(ninput_items);
+                return ninput_items;
+            case 1:  // pull-in: skip samples until the incoming code is aligned with the local replica
+                {
+                    int64_t acq_trk_diff_samples = static_cast<int64_t>(d_sample_counter) - static_cast<int64_t>(d_acq_sample_stamp);
+                    double delta_trk_to_acq_prn_start_samples = static_cast<double>(acq_trk_diff_samples) - d_acq_code_phase_samples;
+                    d_code_freq_chips = d_code_chip_rate;
+                    d_code_phase_step_chips = d_code_freq_chips / trk_parameters.fs_in;
+                    d_code_phase_rate_step_chips = 0.0;
+                    double T_chip_mod_seconds = 1.0 / d_code_freq_chips;
+                    double T_prn_mod_seconds = T_chip_mod_seconds * static_cast<double>(d_code_length_chips);
+                    double T_prn_mod_samples = T_prn_mod_seconds * trk_parameters.fs_in;
+                    d_acq_code_phase_samples = T_prn_mod_samples - std::fmod(delta_trk_to_acq_prn_start_samples, T_prn_mod_samples);
+                    d_current_prn_length_samples = std::round(T_prn_mod_samples);
+                    int32_t samples_offset = std::round(d_acq_code_phase_samples);
+                    d_acc_carrier_phase_rad -= d_carrier_phase_step_rad * static_cast<double>(samples_offset);
+                    d_state = 2;
+                    d_sample_counter += samples_offset;
+                    return samples_offset;
+                }
+            case 2:  // wide tracking
+                {
+                    do_correlation_step(in);
+                    if (d_veml)
+                        {
+                            d_VE_accu = d_correlator_outs[0];
+                            d_VL_accu = d_correlator_outs[4];
+                        }
+                    d_E_accu = d_correlator_outs[d_veml ? 1 : 0];
+                    d_P_accu = d_correlator_outs[d_veml ? 2 : 1];
+                    d_L_accu = d_correlator_outs[d_veml ? 3 : 2];
+                    if (!cn0_and_tracking_lock_status(d_code_period))
+                        {
+                            clear_tracking_vars();
+                            d_state = 0;  // loss of lock
+                        }
+                    else
+                        {
+                            run_dll_pll();
+                            update_tracking_vars();
+                            // tracking results for the telemetry decoder (:1730-1770)
+                            current_synchro_data.Prompt_I = static_cast<double>(d_P_accu.real());
+                            current_synchro_data.Prompt_Q = static_cast<double>(d_P_accu.imag());
+                            current_synchro_data.Code_phase_samples = d_rem_code_phase_samples;
+                            current_synchro_data.Carrier_phase_rads = d_acc_carrier_phase_rad;
+                            current_synchro_data.Carrier_Doppler_hz = d_carrier_doppler_hz;
+                            current_synchro_data.CN0_dB_hz = d_CN0_SNV_dB_Hz;
+                            current_synchro_data.correlation_length_ms = d_correlation_length_ms;
+                            current_synchro_data.Flag_valid_symbol_output = true;
+                        }
+                    break;
+                }
+            default:
+                break;
+            }
+        const int consumed = d_current_prn_length_samples;
+        d_sample_counter += static_cast<uint64_t>(d_current_prn_length_samples);
+        if (current_synchro_data.Flag_valid_symbol_output)
+            {
+                current_synchro_data.System = d_acquisition_gnss_synchro->System;
+                current_synchro_data.Signal[0] = d_acquisition_gnss_synchro->Signal[0];
+                current_synchro_data.Signal[1] = d_acquisition_gnss_synchro->Signal[1];
+                current_synchro_data.PRN = d_acquisition_gnss_synchro->PRN;
+                current_synchro_data.Channel_ID = d_acquisition_gnss_synchro->Channel_ID;
+                current_synchro_data.fs = static_cast<int64_t>(trk_parameters.fs_in);
+                current_synchro_data.Tracking_sample_counter = d_sample_counter;
+                *out = current_synchro_data;
+                *produced = 1;
+            }
+        return consumed;
+    }
+
+    // observers for tests / the adapter
+    int32_t state() const { return d_state; }
+    double carrier_doppler_hz() const { return d_carrier_doppler_hz; }
+    double code_freq_chips() const { return d_code_freq_chips; }
+    double cn0_db_hz() const { return d_CN0_SNV_dB_Hz; }
+    double carrier_lock_test() const { return d_carrier_lock_test; }
+    double rem_code_phase_samples() const { return d_rem_code_phase_samples; }
+    uint64_t sample_counter() const { return d_sample_counter; }
+    const std::vector<gr_complex>& correlator_outs() const { return d_correlator_outs; }
+    const std::vector<int>& events() const { return d_events; }
+    gc_status last_status() const { return multicorrelator_cpu.last_status(); }
+
+private:
+    void set_tap_shifts()
+    {
+        // (:372-390, :720-732)
+        const float spc = static_cast<float>(d_code_samples_per_chip);
+        if (d_veml)
+            {
+                d_local_code_shift_chips[0] = -trk_parameters.very_early_late_space_chips * spc;
+                d_local_code_shift_chips[1] = -trk_parameters.early_late_space_chips * spc;
+                d_local_code_shift_chips[2] = 0.0;
+                d_local_code_shift_chips[3] = trk_parameters.early_late_space_chips * spc;
+                d_local_code_shift_chips[4] = trk_parameters.very_early_late_space_chips * spc;
+            }
+        else
+            {
+                d_local_code_shift_chips[0] = -trk_parameters.early_late_space_chips * spc;
+                d_local_code_shift_chips[1] = 0.0;
+                d_local_code_shift_chips[2] = trk_parameters.early_late_space_chips * spc;
+            }
+    }
+
+    //! (:886-911) -- the hot path: one launch of the HIP multicorrelator
+    void do_correlation_step(const gr_complex* input_samples)
+    {
+        multicorrelator_cpu.set_input_output_vectors(d_correlator_outs.data(), input_samples);
+        multicorrelator_cpu.Carrier_wipeoff_multicorrelator_resampler(
+            d_rem_carr_phase_rad,
+            d_carrier_phase_step_rad, d_carrier_phase_rate_step_rad,
+            static_cast<float>(d_rem_code_phase_chips) * static_cast<float>(d_code_samples_per_chip),
+            static_cast<float>(d_code_phase_step_chips) * static_cast<float>(d_code_samples_per_chip),
+            static_cast<float>(d_code_phase_rate_step_chips) * static_cast<float>(d_code_samples_per_chip),
+            trk_parameters.vector_length);
+    }
+
+    //! (:914-973)
+    void run_dll_pll()
+    {
+        if (d_cloop)
+            d_carr_phase_error_hz = pll_cloop_two_quadrant_atan(d_P_accu) / PI_2;
+        else
+            d_carr_phase_error_hz = pll_four_quadrant_atan(d_P_accu) / PI_2;
+        if ((d_pull_in_transitory == true and trk_parameters.enable_fll_pull_in == true) or trk_parameters.enable_fll_steady_state)
+            {
+                d_carr_freq_error_hz = fll_four_quadrant_atan(d_P_accu_old, d_P_accu, 0, d_current_correlation_time_s) / PI_2;
+                d_P_accu_old = d_P_accu;
+                if ((d_pull_in_transitory == true and trk_parameters.enable_fll_pull_in == true))
+                    d_carr_error_filt_hz = d_carrier_loop_filter.get_carrier_error(d_carr_freq_error_hz, 0, d_current_correlation_time_s);
+                else
+                    d_carr_error_filt_hz = d_carrier_loop_filter.get_carrier_error(d_carr_freq_error_hz, d_carr_phase_error_hz, d_current_correlation_time_s);
+            }
+        else
+            {
+                d_carr_error_filt_hz = d_carrier_loop_filter.get_carrier_error(0, d_carr_phase_error_hz, d_current_correlation_time_s);
+            }
+        d_carrier_doppler_hz = d_carr_error_filt_hz;
+        if (d_veml)
+            d_code_error_chips = dll_nc_vemlp_normalized(d_VE_accu, d_E_accu, d_L_accu, d_VL_accu);
+        else
+            d_code_error_chips = dll_nc_e_minus_l_normalized(d_E_accu, d_L_accu);
+        d_code_error_filt_chips = d_code_loop_filter.apply(d_code_error_chips);
+        d_code_freq_chips = (1.0 + (d_carrier_doppler_hz / d_signal_carrier_freq)) * d_code_chip_rate - d_code_error_filt_chips;
+    }
+
+    //! (:976-995)
+    void clear_tracking_vars()
+    {
+        std::fill(d_correlator_outs.begin(), d_correlator_outs.end(), gr_complex(0.0, 0.0));
+        d_P_accu_old = gr_complex(0.0, 0.0);
+        d_carr_phase_error_hz = 0.0;
+        d_carr_freq_error_hz = 0.0;
+        d_carr_error_filt_hz = 0.0;
+        d_code_error_chips = 0.0;
+        d_code_error_filt_chips = 0.0;
+        d_carrier_phase_rate_step_rad = 0.0;
+        d_code_phase_rate_step_chips = 0.0;
+        d_carr_ph_history.clear();
+        d_code_ph_history.clear();
+    }
+
+    //! rate smoother used by both NCOs when high_dyn is set (:1016-1033, :1047-1064): mean of the
+    //! newer half minus mean of the older half of a 2*smoother_length history, per sample
+    double smoothed_rate(std::deque<std::pair<double, double>>& hist, double value, double samples, double current)
+    {
+        hist.push_back(std::pair<double, double>(value, samples));
+        if (hist.size() > d_carr_ph_history_cap) hist.pop_front();
+        if (hist.size() < d_carr_ph_history_cap) return current;
+        double tmp_cp1 = 0.0, tmp_cp2 = 0.0, tmp_samples = 0.0;
+        const unsigned int sl = trk_parameters.smoother_length;
+        for (unsigned int k = 0; k < sl; k++)
+            {
+                tmp_cp1 += hist[k].first;
+                tmp_cp2 += hist[sl * 2 - k - 1].first;
+                tmp_samples += hist[sl * 2 - k - 1].second;
+            }
+        tmp_cp1 /= static_cast<double>(sl);
+        tmp_cp2 /= static_cast<double>(sl);
+        return (tmp_cp2 - tmp_cp1) / tmp_samples;
+    }
+
+    //! (:998-1070)
+    void update_tracking_vars()
+    {
+        T_chip_seconds = 1.0 / d_code_freq_chips;
+        T_prn_seconds = T_chip_seconds * static_cast<double>(d_code_length_chips);
+        T_prn_samples = T_prn_seconds * trk_parameters.fs_in;
+        K_blk_samples = T_prn_samples + d_rem_code_phase_samples;
+        d_current_prn_length_samples = static_cast<int32_t>(std::floor(K_blk_samples));
+        d_carrier_phase_step_rad = PI_2 * d_carrier_doppler_hz / trk_parameters.fs_in;
+        if (trk_parameters.high_dyn)
+            d_carrier_phase_rate_step_rad = smoothed_rate(d_carr_ph_history, d_carrier_phase_step_rad, static_cast<double>(d_current_prn_length_samples), d_carrier_phase_rate_step_rad);
+        const double n = static_cast<double>(d_current_prn_length_samples);
+        d_rem_carr_phase_rad += static_cast<float>(d_carrier_phase_step_rad * n + 0.5 * d_carrier_phase_rate_step_rad * n * n);
+        d_rem_carr_phase_rad = std::fmod(d_rem_carr_phase_rad, PI_2);
+        d_acc_carrier_phase_rad -= (d_carrier_phase_step_rad * n + 0.5 * d_carrier_phase_rate_step_rad * n * n);
+        d_code_phase_step_chips = d_code_freq_chips / trk_parameters.fs_in;
+        if (trk_parameters.high_dyn)
+            d_code_phase_rate_step_chips = smoothed_rate(d_code_ph_history, d_code_phase_step_chips, n, d_code_phase_rate_step_chips);
+        d_rem_code_phase_samples = K_blk_samples - n;
+        d_rem_code_phase_chips = d_code_freq_chips * d_rem_code_phase_samples / trk_parameters.fs_in;
+    }
+
+    //! (:839-878)
+    bool cn0_and_tracking_lock_status(double coh_integration_time_s)
+    {
+        if (d_cn0_estimation_counter < trk_parameters.cn0_samples)
+            {
+                d_Prompt_buffer[d_cn0_estimation_counter] = d_P_accu;
+                d_cn0_estimation_counter++;
+                return true;
+            }
+        d_cn0_estimation_counter = 0;
+        d_CN0_SNV_dB_Hz = cn0_svn_estimator(d_Prompt_buffer.data(), trk_parameters.cn0_samples, coh_integration_time_s);
+        d_carrier_lock_test = carrier_lock_detector(d_Prompt_buffer.data(), trk_parameters.cn0_samples);
+        if (!d_pull_in_transitory)
+            {
+                if (d_carrier_lock_test < d_carrier_lock_threshold or d_CN0_SNV_dB_Hz < trk_parameters.cn0_min)
+                    d_carrier_lock_fail_counter++;
+                else if (d_carrier_lock_fail_counter > 0)
+                    d_carrier_lock_fail_counter--;
+            }
+        if (d_carrier_lock_fail_counter > trk_parameters.max_lock_fail)
+            {
+                d_events.push_back(3);  // 3 -> loss of lock
+                d_carrier_lock_fail_counter = 0;
+                return false;
+            }
+        return true;
+    }
+
+    const double PI_2 = 6.283185307179586;  // GPS_TWO_PI
+
+    Dll_Pll_Conf trk_parameters;
+    std::mutex d_setlock;
+    std::string signal_type;
+    bool d_veml = false;
+    bool d_cloop = true;
+    bool d_pull_in_transitory = true;
+    uint32_t d_channel = 0;
+    Gnss_Synchro* d_acquisition_gnss_synchro = nullptr;
+    double d_signal_carrier_freq = 0.0;
+    double d_code_period = 0.0;
+    double d_code_chip_rate = 0.0;
+    uint32_t d_code_length_chips = 0;
+    uint32_t d_code_samples_per_chip = 0;
+    int32_t d_symbols_per_bit = 1;
+    int32_t d_correlation_length_ms = 1;
+    int32_t d_n_correlator_taps = 3;
+    int32_t d_state = 0;
+    std::vector<float> d_tracking_code;
+    std::vector<float> d_local_code_shift_chips;
+    std::vector<gr_complex> d_correlator_outs;
+    Hip_Multicorrelator_Real_Codes multicorrelator_cpu;
+    gr_complex d_VE_accu, d_E_accu, d_P_accu, d_P_accu_old, d_L_accu, d_VL_accu;
+    Tracking_loop_filter d_code_loop_filter;
+    Tracking_FLL_PLL_filter d_carrier_loop_filter;
+    double d_acq_code_phase_samples = 0.0;
+    double d_acq_carrier_doppler_hz = 0.0;
+    uint64_t d_acq_sample_stamp = 0;
+    double d_current_correlation_time_s = 0.0;
+    double d_carr_phase_error_hz = 0.0, d_carr_freq_error_hz = 0.0, d_carr_error_filt_hz = 0.0;
+    double d_code_error_chips = 0.0, d_code_error_filt_chips = 0.0;
+    double d_code_freq_chips = 0.0;
+    double d_carrier_doppler_hz = 0.0;
+    double d_acc_carrier_phase_rad = 0.0;
+    double d_rem_code_phase_chips = 0.0;
+    double d_rem_code_phase_samples = 0.0;
+    double d_code_phase_step_chips = 0.0, d_code_phase_rate_step_chips = 0.0;
+    double d_carrier_phase_step_rad = 0.0, d_carrier_phase_rate_step_rad = 0.0;
+    float d_rem_carr_phase_rad = 0.0f;
+    std::deque<std::pair<double, double>> d_carr_ph_history, d_code_ph_history;
+    size_t d_carr_ph_history_cap = 20;
+    double T_chip_seconds = 0.0, T_prn_seconds = 0.0, T_prn_samples = 0.0, K_blk_samples = 0.0;
+    int32_t d_current_prn_length_samples = 0;
+    uint64_t d_sample_counter = 0;
+    int32_t d_cn0_estimation_counter = 0;
+    int32_t d_carrier_lock_fail_counter = 0;
+    double d_carrier_lock_test = 1.0;
+    double d_CN0_SNV_dB_Hz = 0.0;
+    double d_carrier_lock_threshold = 0.85;
+    std::vector<gr_complex> d_Prompt_buffer;
+    std::vector<int> d_events;
+};
+
+#endif  // GNSSCORR_HIP_DLL_PLL_VEML_TRACKING_H_

@@ -94,3 +94,12 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".cc")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f == "sharding.py", os.path.join(dirpath, f)
+
+
+def test_loop_maths_against_reference_unit_test_vectors():
+    """Host-side loop maths of the tracking adapter (tracking_loop_maths.h) against the expected values of the
+    reference's TrackingLoopFilterTest (tracking_loop_filter_test.cc) and closed forms; CPU only."""
+    d = os.path.join(ROOT, "gnss-sdr-1_amd", "adapter")
+    subprocess.check_call(["make", "-s", "-C", d, "loop_maths_selftest"])
+    p = subprocess.run([os.path.join(d, "loop_maths_selftest")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "loop maths self-test passed" in p.stdout, p.stdout + p.stderr

@@ -51,3 +51,15 @@ def test_two_step_acquisition_matches_reference_formulas(gctx, oracle):
     acq.set_step_two(False)
     assert acq.num_doppler_bins == 40
     acq.close()
+
+
+def test_cpp_closed_loop_tracking_selftest():
+    """Acquisition -> hand-over -> DLL/PLL tracking through the C++ drop-in layer (BASELINE configs[0] shape),
+    plus Galileo E1 / BeiDou B1I hand-overs and a loss-of-lock case (tracking_selftest.cpp)."""
+    exe = os.path.join(ROOT, "gnss-sdr-1_amd", "adapter", "tracking_selftest")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(p.stdout, p.stderr)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "tracking self-test passed" in p.stdout

@@ -140,14 +140,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (not used by the driver): several ranks on ONE GPU with gloo, to exercise the N > 1 code path
+    force_dev = os.environ.get("BENCH_FORCE_DEVICE")
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = int(force_dev) if force_dev is not None else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else None
 
-    ctx = gnsscorr.Context(local_rank)
+    ctx = gnsscorr.Context(dev_index)
     E = args.epochs
     n_stream = E * N_EPOCH + 64
     shifts = np.array([-0.5, 0.0, 0.5], np.float32)
@@ -197,7 +205,7 @@ def main():
         ev[i][1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
+    elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

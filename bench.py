@@ -243,6 +243,33 @@ def main():
                 "ms_per_step": shared_ms, "note": "32 channels read one RF stream; input served from L2/Infinity Cache"}
         extra["realtime_factor_256ch"] = value / world / (256 * FS / 1e6)
 
+        # ---- int16 IQ in HBM (cshort front-end samples, converted on load): 4 B per channel-sample ----
+        if not args.no_shared:
+            b16 = gnsscorr.TrackingBatch(ctx, N_CHANNELS, N_TAPS, CODE_LEN)
+            b16.set_input_format(gnsscorr.GC_IQ_I16)
+            q_streams = []
+            for ch in range(N_CHANNELS):
+                qs = torch.clamp(torch.round(streams[ch] * 600.0), -32768, 32767).to(torch.int16).contiguous()
+                q_streams.append(qs)
+                b16.set_code(ch, codes[ch], shifts)
+                b16.set_input_dev(ch, qs.data_ptr(), n_stream)
+            b16.set_nominal_length(N_EPOCH)
+            for _ in range(2):
+                b16.run_dev(E, d_params.data_ptr(), d_out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            i0.record()
+            for _ in range(args.steps):
+                b16.run_dev(E, d_params.data_ptr(), d_out.data_ptr(), stream)
+            i1.record()
+            torch.cuda.synchronize()
+            i16_ms = i0.elapsed_time(i1) / args.steps
+            extra["int16_input"] = {"value": samples_per_step / (i16_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": i16_ms,
+                "hbm_gbps": 4.0 * samples_per_step / (i16_ms * 1e-3) / 1e9,
+                "note": "same workload with lv_16sc_t IQ in HBM (distinct buffer per channel), 4 B per channel-sample"}
+            b16.close()
+            del q_streams
+
         # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----
         if not args.no_acq:
             acq = gnsscorr.PcpsAcquisition(ctx, 32, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,

@@ -44,6 +44,7 @@ struct gc_trk_batch
     int n_channels = 0, n_taps = 0, max_code_len = 0, mode = TRK_MODE_PLAIN;
     int lds_table_floats = 0;
     int nominal_len = 0;
+    int iq_format = GC_IQ_F32;
     int forced_slices = 0;
     std::vector<TrkChan> h_chans;
     bool chans_dirty = true;
@@ -163,10 +164,29 @@ gc_status gc_trk_batch_set_input_dev(gc_trk_batch* b, int ch, const void* dev_iq
 {
     GC_REQUIRE(b && dev_iq, "gc_trk_batch_set_input_dev: NULL argument");
     GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_input_dev: channel %d out of range", ch);
-    GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) & 7) == 0, "gc_trk_batch_set_input_dev: IQ pointer must be 8-byte aligned");
-    b->h_chans[ch].iq = static_cast<const float2*>(dev_iq);
+    const uintptr_t es = b->iq_format == GC_IQ_F32 ? 8 : b->iq_format == GC_IQ_I16 ? 4 : 2;
+    GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) % es) == 0, "gc_trk_batch_set_input_dev: IQ pointer must be aligned to one sample (%d bytes)", (int)es);
+    b->h_chans[ch].iq = dev_iq;
     b->h_chans[ch].n_iq = n_samples;
     b->chans_dirty = true;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_input_format(gc_trk_batch* b, int iq_format)
+{
+    GC_REQUIRE(b, "gc_trk_batch_set_input_format: NULL argument");
+    GC_REQUIRE(iq_format == GC_IQ_F32 || iq_format == GC_IQ_I16 || iq_format == GC_IQ_I8, "gc_trk_batch_set_input_format: unknown format %d", iq_format);
+    if (iq_format != b->iq_format)
+        {
+            // pointers registered so far were checked against the old sample size
+            for (auto& c : b->h_chans)
+                {
+                    c.iq = nullptr;
+                    c.n_iq = 0;
+                }
+            b->chans_dirty = true;
+        }
+    b->iq_format = iq_format;
     return GC_OK;
 }
 
@@ -209,7 +229,7 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
                     b->partial_cap = need;
                 }
         }
-    hipError_t e = trk_launch(b->n_taps, b->mode, st, b->d_chans, dev_params, static_cast<float2*>(dev_out), b->d_partial,
+    hipError_t e = trk_launch(b->n_taps, b->mode, b->iq_format, st, b->d_chans, dev_params, static_cast<float2*>(dev_out), b->d_partial,
         b->n_channels, n_epochs, n_slices, b->lds_table_floats);
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
     return GC_OK;
@@ -368,7 +388,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     int n_slices = chunks / 2;
     if (n_slices < 1) n_slices = 1;
     if (n_slices > c->partial_slices) n_slices = c->partial_slices;
-    hipError_t e = trk_launch(c->n_corr, mode, st, &c->d_stage->chan, &c->d_stage->params, c->d_out, c->d_partial, 1, 1,
+    hipError_t e = trk_launch(c->n_corr, mode, GC_IQ_F32, st, &c->d_stage->chan, &c->d_stage->params, c->d_out, c->d_partial, 1, 1,
         n_slices, L + 64);
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
     GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, sizeof(float2) * c->n_corr, hipMemcpyDeviceToHost, st));

@@ -9,7 +9,7 @@
 // per-channel descriptor (device memory)
 struct TrkChan
 {
-    const float2* iq;          // IQ base of the channel's RF stream (HBM)
+    const void* iq;            // IQ base of the channel's RF stream (HBM), samples in the batch's gc_iq_format
     unsigned long long n_iq;   // samples available at iq
     const float* code;         // code table (HBM), code_len floats
     int code_len;
@@ -27,7 +27,7 @@ enum
 // Enqueues the multicorrelator for n_channels x n_epochs jobs on `st`.
 // lds_table_floats: capacity of the LDS code window (>= longest code_len).
 // partial: workspace of n_channels*n_epochs*n_slices*n_taps float2 (n_slices > 1 only).
-hipError_t trk_launch(int n_taps, int mode, hipStream_t st, const TrkChan* chans,
+hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const TrkChan* chans,
     const gc_epoch_params* params, float2* out, float2* partial,
     int n_channels, int n_epochs, int n_slices, int lds_table_floats);
 

@@ -102,6 +102,40 @@ static __device__ __forceinline__ void carrier_at(int n, double theta0, double d
 // native vector types: loads through an address-space-qualified pointer need plain (non-class) types
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef signed char i8x2 __attribute__((ext_vector_type(2)));
+typedef signed char i8x4 __attribute__((ext_vector_type(4)));
+
+// IQ sample formats in HBM (gc_iq_format).  Integer samples are converted with a plain cast, like the
+// reference's volk_gnsssdr_16ic_convert_32fc / interleaved-byte adapters do before the float correlators,
+// so the arithmetic downstream is identical; only the bytes per sample change (8 / 4 / 2).
+template <int FMT>
+struct IqFmt;
+template <>
+struct IqFmt<GC_IQ_F32>
+{
+    typedef f32x2 elem;
+    typedef f32x4 pair;
+    static __device__ __forceinline__ f32x4 cvt(pair v) { return v; }
+    static __device__ __forceinline__ f32x2 cvt1(elem v) { return v; }
+};
+template <>
+struct IqFmt<GC_IQ_I16>
+{
+    typedef i16x2 elem;
+    typedef i16x4 pair;
+    static __device__ __forceinline__ f32x4 cvt(pair v) { return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
+    static __device__ __forceinline__ f32x2 cvt1(elem v) { return f32x2{(float)v.x, (float)v.y}; }
+};
+template <>
+struct IqFmt<GC_IQ_I8>
+{
+    typedef i8x2 elem;
+    typedef i8x4 pair;
+    static __device__ __forceinline__ f32x4 cvt(pair v) { return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
+    static __device__ __forceinline__ f32x2 cvt1(elem v) { return f32x2{(float)v.x, (float)v.y}; }
+};
 
 // (int)floorf(x) in one instruction (v_floor_f32 + v_cvt_i32_f32 otherwise)
 static __device__ __forceinline__ int floor_to_int(float x)
@@ -114,8 +148,8 @@ static __device__ __forceinline__ int floor_to_int(float x)
 // Main loop over the chunks [c0, c1) of one (channel, epoch, slice).
 //   WINDOWED: table[] holds code[(lo + k) mod L], indices need no wrap
 //   else    : table[] holds code[0..L), indices are wrapped with the reference's modulo
-template <int NTAPS, bool HDR, bool HDC, bool WINDOWED>
-static __device__ __forceinline__ void trk_loop(const GC_GLOBAL f32x2* __restrict__ base, const float* __restrict__ table,
+template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT>
+static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
     int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
     float (&accr)[NTAPS], float (&acci)[NTAPS])
@@ -147,11 +181,12 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL f32x2* __restric
     auto chunk_is_full = [&](int c) { return (c > 0 || a == 0) && (c + 1) * TRK_CHUNK <= V; };
     auto load_full = [&](int c) -> f32x4 {
         // uniform chunk base + constant per-lane offset: SGPR-base global loads
-        const GC_GLOBAL char* p = reinterpret_cast<const GC_GLOBAL char*>(base) + (size_t)c * (TRK_CHUNK * 8) + tid * 16;
+        typedef typename IqFmt<FMT>::pair pair_t;
+        const GC_GLOBAL char* p = reinterpret_cast<const GC_GLOBAL char*>(base) + (size_t)c * (TRK_CHUNK / 2 * sizeof(pair_t)) + tid * sizeof(pair_t);
 #if TRK_NT
-        return __builtin_nontemporal_load(reinterpret_cast<const GC_GLOBAL f32x4*>(p));
+        return IqFmt<FMT>::cvt(__builtin_nontemporal_load(reinterpret_cast<const GC_GLOBAL pair_t*>(p)));
 #else
-        return *reinterpret_cast<const GC_GLOBAL f32x4*>(p);
+        return IqFmt<FMT>::cvt(*reinterpret_cast<const GC_GLOBAL pair_t*>(p));
 #endif
     };
     auto load_masked = [&](int c) -> f32x4 {
@@ -159,13 +194,13 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL f32x2* __restric
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
         if (v >= a && v < V)
             {
-                f32x2 s = base[v];
+                f32x2 s = IqFmt<FMT>::cvt1(base[v]);
                 x.x = s.x;
                 x.y = s.y;
             }
         if (v + 1 >= a && v + 1 < V)
             {
-                f32x2 s = base[v + 1];
+                f32x2 s = IqFmt<FMT>::cvt1(base[v + 1]);
                 x.z = s.x;
                 x.w = s.y;
             }
@@ -320,7 +355,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL f32x2* __restric
 #ifndef TRK_WAVES
 #define TRK_WAVES 8  // minimum waves per SIMD the register allocator must leave room for (<= 64 VGPRs)
 #endif
-template <int NTAPS, bool HDR, bool HDC>
+template <int NTAPS, bool HDR, bool HDC, int FMT>
 __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_kernel(
     const TrkChan* __restrict__ chans, const gc_epoch_params* __restrict__ params,
     float2* __restrict__ out, float2* __restrict__ partial,
@@ -350,10 +385,11 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_ke
     const int N = p.n_samples;
     const int L = cd.code_len;
 
-    const float2* iq = cd.iq + p.sample_offset;
-    const int a = (int)((reinterpret_cast<uintptr_t>(iq) >> 3) & 1);  // 1: window starts on the odd half of a 16-byte pair
-    // 16-byte aligned; sample n lives at base[n + a].  IQ lives in HBM: global (not flat) loads
-    const GC_GLOBAL f32x2* base = (const GC_GLOBAL f32x2*)(iq - a);
+    typedef typename IqFmt<FMT>::elem elem_t;
+    const elem_t* iq = static_cast<const elem_t*>(cd.iq) + p.sample_offset;
+    const int a = (int)((reinterpret_cast<uintptr_t>(iq) / sizeof(elem_t)) & 1);  // 1: window starts on the odd half of a sample pair
+    // pair-aligned; sample n lives at base[n + a].  IQ lives in HBM: global (not flat) loads
+    const GC_GLOBAL elem_t* base = (const GC_GLOBAL elem_t*)(iq - a);
     const int V = N + a;
     const int n_chunks = (V + TRK_CHUNK - 1) / TRK_CHUNK;
     const int cps = (n_chunks + n_slices - 1) / n_slices;
@@ -479,9 +515,9 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_ke
     for (int t = 0; t < NTAPS; t++) accr[t] = acci[t] = 0.0f;
 
     if (windowed)
-        trk_loop<NTAPS, HDR, HDC, true>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, true, FMT>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
     else
-        trk_loop<NTAPS, HDR, HDC, false>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, false, FMT>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread
@@ -534,23 +570,23 @@ __global__ void trk_finish_kernel(const float2* __restrict__ partial, float2* __
 // -----------------------------------------------------------------------------
 // launcher
 // -----------------------------------------------------------------------------
-template <int NTAPS>
-static hipError_t launch_ntaps(int mode, dim3 grid, size_t lds_bytes, hipStream_t st,
+template <int NTAPS, int FMT>
+static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStream_t st,
     const TrkChan* chans, const gc_epoch_params* params, float2* out, float2* partial,
     int n_channels, int n_epochs, int n_slices, int lds_table_floats)
 {
     switch (mode)
         {
         case TRK_MODE_PLAIN:
-            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false>), grid, dim3(TRK_THREADS), lds_bytes, st,
+            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
                 chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
             break;
         case TRK_MODE_HD_RESAMPLER:
-            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, true, false>), grid, dim3(TRK_THREADS), lds_bytes, st,
+            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, true, false, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
                 chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
             break;
         case TRK_MODE_HD_FULL:
-            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, true, true>), grid, dim3(TRK_THREADS), lds_bytes, st,
+            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, true, true, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
                 chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
             break;
         default:
@@ -559,7 +595,25 @@ static hipError_t launch_ntaps(int mode, dim3 grid, size_t lds_bytes, hipStream_
     return hipGetLastError();
 }
 
-hipError_t trk_launch(int n_taps, int mode, hipStream_t st, const TrkChan* chans,
+template <int NTAPS>
+static hipError_t launch_ntaps(int mode, int fmt, dim3 grid, size_t lds_bytes, hipStream_t st,
+    const TrkChan* chans, const gc_epoch_params* params, float2* out, float2* partial,
+    int n_channels, int n_epochs, int n_slices, int lds_table_floats)
+{
+    switch (fmt)
+        {
+        case GC_IQ_F32:
+            return launch_ntaps_fmt<NTAPS, GC_IQ_F32>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+        case GC_IQ_I16:
+            return launch_ntaps_fmt<NTAPS, GC_IQ_I16>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+        case GC_IQ_I8:
+            return launch_ntaps_fmt<NTAPS, GC_IQ_I8>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+        default:
+            return hipErrorInvalidValue;
+        }
+}
+
+hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const TrkChan* chans,
     const gc_epoch_params* params, float2* out, float2* partial,
     int n_channels, int n_epochs, int n_slices, int lds_table_floats)
 {
@@ -569,7 +623,7 @@ hipError_t trk_launch(int n_taps, int mode, hipStream_t st, const TrkChan* chans
     hipError_t e;
 #define CASE(NT)                                                                                       \
     case NT:                                                                                           \
-        e = launch_ntaps<NT>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, \
+        e = launch_ntaps<NT>(mode, iq_format, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, \
             n_slices, lds_table_floats);                                                               \
         break;
     switch (n_taps)

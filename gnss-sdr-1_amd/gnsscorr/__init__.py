@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("GNSSCORR_LIB", os.path.join(os.path.dirname(_HERE), "
 
 GC_OK, GC_ERR_INVALID, GC_ERR_NO_DEVICE, GC_ERR_HIP, GC_ERR_STATE = range(5)
 GC_MAX_TAPS = 8
+GC_IQ_F32, GC_IQ_I16, GC_IQ_I8 = range(3)
 
 
 class GnsscorrError(RuntimeError):
@@ -115,6 +116,7 @@ API = {
     "gc_trk_batch_destroy": (C.c_int, [_vp]),
     "gc_trk_batch_set_code": (C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp]),
     "gc_trk_batch_set_shifts": (C.c_int, [_vp, C.c_int, _fp]),
+    "gc_trk_batch_set_input_format": (C.c_int, [_vp, C.c_int]),
     "gc_trk_batch_set_input_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
     "gc_trk_batch_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "gc_trk_batch_run": (C.c_int, [_vp, C.c_int, _vp, _fp]),
@@ -354,6 +356,9 @@ class TrackingBatch:
         shifts = np.ascontiguousarray(shifts_chips, np.float32)
         assert shifts.size == self.n_taps
         _check(load_library().gc_trk_batch_set_shifts(self._h, ch, _f32p(shifts)))
+
+    def set_input_format(self, iq_format):
+        _check(load_library().gc_trk_batch_set_input_format(self._h, int(iq_format)))
 
     def set_input_dev(self, ch, dev_ptr, n_samples):
         _check(load_library().gc_trk_batch_set_input_dev(self._h, ch, _vp(dev_ptr), int(n_samples)))

@@ -124,6 +124,17 @@ void gc_epoch_params_fill(gc_epoch_params* p, uint64_t sample_offset,
     float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
     int signal_length_samples);
 
+/* IQ sample formats accepted from HBM.  Integer formats are what SDR front-ends deliver and the reference
+ * converts to gr_complex before its float correlators (volk_gnsssdr_16ic_convert_32fc,
+ * pcps_acquisition.cc:676-679; data_type_adapter blocks): the engine converts on load (plain cast), so
+ * results equal the float path on the converted samples while HBM bytes per sample drop from 8 to 4 / 2. */
+typedef enum
+{
+    GC_IQ_F32 = 0, /* interleaved float32 (re, im): gr_complex / lv_32fc_t */
+    GC_IQ_I16 = 1, /* interleaved int16   (re, im): lv_16sc_t ("cshort") */
+    GC_IQ_I8 = 2   /* interleaved int8    (re, im): lv_8sc_t  ("cbyte") */
+} gc_iq_format;
+
 typedef struct gc_trk_batch gc_trk_batch;
 /* n_channels channels with n_taps correlator taps each; code tables up to
  * max_code_length entries.  high_dyn selects the high-dynamics resampler +
@@ -136,8 +147,10 @@ gc_status gc_trk_batch_destroy(gc_trk_batch* b);
 gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int code_length,
     const float* shifts_chips);
 gc_status gc_trk_batch_set_shifts(gc_trk_batch* b, int ch, const float* shifts_chips);
-/* Points channel `ch` at its IQ samples in HBM (n_samples complex).  Channels
- * of one RF stream may share the same pointer. */
+/* Sample format of every channel's IQ buffer (default GC_IQ_F32). */
+gc_status gc_trk_batch_set_input_format(gc_trk_batch* b, int iq_format);
+/* Points channel `ch` at its IQ samples in HBM (n_samples complex samples of the batch's format,
+ * aligned to one sample).  Channels of one RF stream may share the same pointer. */
 gc_status gc_trk_batch_set_input_dev(gc_trk_batch* b, int ch, const void* dev_iq, uint64_t n_samples);
 /* Correlates n_epochs epochs of every channel.  dev_params: n_channels*n_epochs
  * gc_epoch_params, channel-major.  dev_out: n_channels*n_epochs*n_taps complex.

@@ -230,3 +230,33 @@ def test_full_size_properties_cfg2(gctx, oracle):
         p = open_loop_params(truth[ch], fs, 1023, n, n_ep)[k]
         ref = oracle.multicorrelator(sig[p["sample_offset"]:], codes[ch], shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
         assert rel_err(outs[0][ch, k], ref, 1) <= TOL
+
+
+@pytest.mark.parametrize("fmt_name,np_type,scale", [("GC_IQ_I16", np.int16, 600.0), ("GC_IQ_I8", np.int8, 24.0)])
+def test_integer_iq_formats_equal_float_path_on_converted_samples(gctx, oracle, fmt_name, np_type, scale):
+    """cshort / cbyte input (what front-ends deliver; the reference converts them to gr_complex with a plain cast
+    before its float correlators, pcps_acquisition.cc:676-679 / data_type_adapter): the engine converts on load,
+    so results must equal the float path fed with the converted samples."""
+    import gnsscorr
+    import torch
+    fs, n, n_ep = 25_000_000, 25000, 3
+    code = oracle.gps_l1_ca_code(12).astype(np.float32)
+    sig, truth = synth_stream([code], fs, n * n_ep + 16, seed=21, cn0_db_hz=(46.0, 46.0))
+    q = np.clip(np.round(sig.view(np.float32) * scale), np.iinfo(np_type).min, np.iinfo(np_type).max).astype(np_type)  # interleaved re, im
+    sig_f = q.astype(np.float32).view(np.complex64)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    d_q = torch.from_numpy(q).cuda()
+    b = gnsscorr.TrackingBatch(gctx, 1, 3, 1023)
+    b.set_input_format(getattr(gnsscorr, fmt_name))
+    b.set_code(0, code, shifts)
+    recs, refs = [], []
+    for k, p in enumerate(open_loop_params(truth[0], fs, 1023, n, n_ep)):
+        off = p["sample_offset"] + k * 3  # odd and even starts
+        recs.append(gnsscorr.epoch_params(off, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n))
+        refs.append(oracle.multicorrelator(sig_f[off:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n))
+    b.set_input_dev(0, d_q.data_ptr(), sig_f.size)
+    got = b.run(n_ep, gnsscorr.epoch_params_array(recs))[0]
+    b.close()
+    for k in range(n_ep):
+        assert abs(refs[k][1]) > 0.4 * truth[0]["amp"] * scale * n
+        assert rel_err(got[k], refs[k], 1) <= TOL

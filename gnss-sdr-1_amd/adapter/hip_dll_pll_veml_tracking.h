@@ -11,8 +11,9 @@
  * high-dynamics rate smoother, cn0_and_tracking_lock_status (:839-878), the Gnss_Synchro record written
  * per epoch (:1730-1770, :1898-1906).
  * Not mirrored (outside the correlator hot path): telemetry preamble / secondary-code synchronisation and
- * the extended-integration states 3/4 that it enables (the block stays in state 2), binary dumps,
- * the telemetry fault message handler, the pilot (E1-C) component.
+ * the extended-integration states 3/4 that it enables (the block stays in state 2), the .mat conversion of
+ * the dump, the telemetry fault message handler, the pilot (E1-C) component.  The binary dump itself
+ * (log_data, :1128-1250) is written in the reference's record layout.
  *
  * general_work(noutput, ninput_items, input_items, output_items) becomes
  * work(in, ninput_items, out): returns the number of input items consumed (consume_each) and sets
@@ -26,6 +27,7 @@
 #include "tracking_loop_maths.h"
 #include <cmath>
 #include <deque>
+#include <fstream>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -85,7 +87,18 @@ public:
         d_carr_ph_history_cap = 2 * trk_parameters.smoother_length;
     }
 
-    void set_channel(uint32_t channel) { d_channel = channel; }
+    //! set_channel (:1442-1480): with Tracking_XX.dump the binary dump file "<dump_filename><channel>.dat" is opened here
+    void set_channel(uint32_t channel)
+    {
+        d_channel = channel;
+        if (trk_parameters.dump && !d_dump_file.is_open())
+            {
+                std::string name = trk_parameters.dump_filename;
+                name.append(std::to_string(d_channel));
+                name.append(".dat");
+                d_dump_file.open(name.c_str(), std::ios::out | std::ios::binary);
+            }
+    }
     void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) { d_acquisition_gnss_synchro = p_gnss_synchro; }
 
     //! dll_pll_veml_tracking::start_tracking (:549-747)
@@ -192,6 +205,7 @@ public:
                         {
                             run_dll_pll();
                             update_tracking_vars();
+                            log_data();
                             // tracking results for the telemetry decoder (:1730-1770)
                             current_synchro_data.Prompt_I = static_cast<double>(d_P_accu.real());
                             current_synchro_data.Prompt_Q = static_cast<double>(d_P_accu.imag());
@@ -357,6 +371,43 @@ private:
         d_rem_code_phase_chips = d_code_freq_chips * d_rem_code_phase_samples / trk_parameters.fs_in;
     }
 
+    //! log_data (:1128-1250): one packed 96-byte record per epoch, the layout
+    //! src/utils/matlab/libs/dll_pll_veml_read_tracking_dump.m and tracking_dump_reader.cc read
+    void log_data()
+    {
+        if (!d_dump_file.is_open()) return;
+        auto put = [&](const void* p, size_t n) { d_dump_file.write(reinterpret_cast<const char*>(p), n); };
+        float f[7];
+        f[0] = d_veml ? std::abs(d_VE_accu) : 0.0f;
+        f[1] = std::abs(d_E_accu);
+        f[2] = std::abs(d_P_accu);
+        f[3] = std::abs(d_L_accu);
+        f[4] = d_veml ? std::abs(d_VL_accu) : 0.0f;
+        f[5] = d_P_accu.real();  // prompt I
+        f[6] = d_P_accu.imag();  // prompt Q
+        put(f, sizeof f);
+        uint64_t stamp = d_sample_counter + static_cast<uint64_t>(d_current_prn_length_samples);
+        put(&stamp, sizeof stamp);
+        float g[12];
+        g[0] = d_acc_carrier_phase_rad;
+        g[1] = d_carrier_doppler_hz;
+        g[2] = d_carrier_phase_rate_step_rad * trk_parameters.fs_in * trk_parameters.fs_in / PI_2;
+        g[3] = d_code_freq_chips;
+        g[4] = d_code_phase_rate_step_chips * trk_parameters.fs_in * trk_parameters.fs_in;
+        g[5] = d_carr_phase_error_hz;
+        g[6] = d_carr_error_filt_hz;
+        g[7] = d_code_error_chips;
+        g[8] = d_code_error_filt_chips;
+        g[9] = d_CN0_SNV_dB_Hz;
+        g[10] = d_carrier_lock_test;
+        g[11] = d_rem_code_phase_samples;
+        put(g, sizeof g);
+        double stamp_d = static_cast<double>(d_sample_counter + d_current_prn_length_samples);
+        put(&stamp_d, sizeof stamp_d);
+        uint32_t prn_ = d_acquisition_gnss_synchro->PRN;
+        put(&prn_, sizeof prn_);
+    }
+
     //! (:839-878)
     bool cn0_and_tracking_lock_status(double coh_integration_time_s)
     {
@@ -437,6 +488,7 @@ private:
     double d_carrier_lock_threshold = 0.85;
     std::vector<gr_complex> d_Prompt_buffer;
     std::vector<int> d_events;
+    std::ofstream d_dump_file;
 };
 
 #endif  // GNSSCORR_HIP_DLL_PLL_VEML_TRACKING_H_

@@ -7,6 +7,7 @@
 #include "pcps_acquisition_adapters.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <vector>
 
@@ -91,6 +92,11 @@ static void test_gps_acq_then_track()
     config.set_property("Tracking_1C.pll_bw_hz", "40.0");
     config.set_property("Tracking_1C.dll_bw_hz", "2.0");
     config.set_property("Tracking_1C.early_late_space_chips", "0.5");
+    if (const char* dump_dir = std::getenv("GNSSCORR_SELFTEST_DUMP_DIR"))
+        {
+            config.set_property("Tracking_1C.dump", "true");
+            config.set_property("Tracking_1C.dump_filename", std::string(dump_dir) + "/track_ch");
+        }
     Gnss_Synchro syn;
     syn.System = 'G';
     syn.Signal[0] = '1';

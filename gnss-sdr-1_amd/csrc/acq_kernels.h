@@ -68,6 +68,9 @@ int acq_cols_blocks(const AcqFftPlan& plan);
 // phase[bin][n] = float32 running sum of phase_inc[bin] (volk_gnsssdr_s32f_sincos_32fc); out = (cos, sin)
 hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float2* out, int n_bins, int N);
 
+// cshort / cbyte input block -> float complex (n samples)
+hipError_t acq_launch_convert(hipStream_t st, int iq_format, const void* in, float2* out, int n);
+
 hipError_t acq_launch_input_power(hipStream_t st, const float2* x, int n_valid, int N, float* out_power, float* tmp_all,
     int n_sats, size_t tmp_stride);
 

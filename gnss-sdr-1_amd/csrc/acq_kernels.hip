@@ -447,6 +447,27 @@ __global__ void acq_wipeoff_sincos_kernel(const float* __restrict__ phase, float
     out[i] = make_float2(c, s);
 }
 
+// ---- integer input samples -> gr_complex (volk_gnsssdr_16ic_convert_32fc at the head of acquisition_core,
+// pcps_acquisition.cc:676-679): plain casts ----
+template <typename T>
+__global__ void acq_convert_kernel(const T* __restrict__ in, float2* __restrict__ out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float2((float)in[2 * i], (float)in[2 * i + 1]);
+}
+
+hipError_t acq_launch_convert(hipStream_t st, int iq_format, const void* in, float2* out, int n)
+{
+    dim3 grid((n + 255) / 256);
+    if (iq_format == GC_IQ_I16)
+        hipLaunchKernelGGL(acq_convert_kernel<short>, grid, dim3(256), 0, st, static_cast<const short*>(in), out, n);
+    else if (iq_format == GC_IQ_I8)
+        hipLaunchKernelGGL(acq_convert_kernel<signed char>, grid, dim3(256), 0, st, static_cast<const signed char*>(in), out, n);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // ---- input power (pcps_acquisition.cc:703-709) ----
 __global__ __launch_bounds__(1024) void acq_input_power_kernel(const float2* __restrict__ x, int n_valid, int N,
     float* __restrict__ out_power, float* __restrict__ tmp_all, int n_sats, size_t tmp_stride)

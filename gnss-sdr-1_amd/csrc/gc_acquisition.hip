@@ -40,6 +40,8 @@ struct gc_acq
     unsigned* d_blki = nullptr;
     float* d_power = nullptr;
     float2* d_in = nullptr;
+    float2* d_cvt = nullptr;  // converted input block (integer sample formats)
+    int iq_format = GC_IQ_F32;
     gc_acq_result* d_results = nullptr;
     gc_acq_result* h_results = nullptr;  // pinned
     std::vector<char> code_set;
@@ -61,6 +63,7 @@ static void acq_release(gc_acq* a)
     (void)hipFree(a->d_blki);
     (void)hipFree(a->d_power);
     (void)hipFree(a->d_in);
+    (void)hipFree(a->d_cvt);
     (void)hipFree(a->d_results);
     if (a->h_results) (void)hipHostFree(a->h_results);
 }
@@ -147,6 +150,7 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     ACQ_TRY(hipMalloc(&a->d_blki, (size_t)n_sats * a->n_bins_alloc * a->n_blocks * sizeof(unsigned)));
     ACQ_TRY(hipMalloc(&a->d_power, sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_in, N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_cvt, N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_results, (size_t)n_sats * sizeof(gc_acq_result)));
     ACQ_TRY(hipHostMalloc(reinterpret_cast<void**>(&a->h_results), (size_t)n_sats * sizeof(gc_acq_result), hipHostMallocDefault));
     a->code_set.assign(n_sats, 0);
@@ -296,8 +300,16 @@ gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz)
     return GC_OK;
 }
 
-static gc_status acq_enqueue(gc_acq* a, const float2* dev_iq, hipStream_t st)
+static gc_status acq_enqueue(gc_acq* a, const float2* dev_iq_in, hipStream_t st)
 {
+    const float2* dev_iq = dev_iq_in;
+    if (a->iq_format != GC_IQ_F32)
+        {
+            // d_cshort path of acquisition_core (:676-679): convert the block, then the float search
+            hipError_t ec = acq_launch_convert(st, a->iq_format, dev_iq_in, a->d_cvt, (int)a->consumed);
+            if (ec != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: input conversion failed: %s", hipGetErrorString(ec));
+            dev_iq = a->d_cvt;
+        }
     for (int s = 0; s < a->n_sats; s++)
         if (!a->code_set[s]) return gc_fail(GC_ERR_STATE, "gc_acq_dwell: satellite slot %d has no local code", s);
     const size_t N = a->fft_size;
@@ -359,6 +371,14 @@ static gc_status acq_enqueue(gc_acq* a, const float2* dev_iq, hipStream_t st)
     return GC_OK;
 }
 
+gc_status gc_acq_set_input_format(gc_acq* a, int iq_format)
+{
+    GC_REQUIRE(a, "gc_acq_set_input_format: NULL handle");
+    GC_REQUIRE(iq_format == GC_IQ_F32 || iq_format == GC_IQ_I16 || iq_format == GC_IQ_I8, "gc_acq_set_input_format: unknown format %d", iq_format);
+    a->iq_format = iq_format;
+    return GC_OK;
+}
+
 gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream)
 {
     GC_REQUIRE(a && dev_iq, "gc_acq_dwell_enqueue: NULL argument");
@@ -395,7 +415,11 @@ gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_resu
         GC_HIP(hipMemcpyAsync(a->d_in, host_iq, sizeof(float2) * a->consumed, hipMemcpyHostToDevice, a->ctx->stream));
         GC_HIP(hipStreamSynchronize(a->ctx->stream));
     }
-    return gc_acq_dwell_dev(a, a->d_in, host_results, nullptr);
+    const int fmt = a->iq_format;  // the host entry point takes gr_complex, whatever the device format is
+    a->iq_format = GC_IQ_F32;
+    gc_status s = gc_acq_dwell_dev(a, a->d_in, host_results, nullptr);
+    a->iq_format = fmt;
+    return s;
 }
 
 gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid)

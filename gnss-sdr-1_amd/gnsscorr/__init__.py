@@ -134,6 +134,7 @@ API = {
     "gc_acq_set_local_code": (C.c_int, [_vp, C.c_int, _fp]),
     "gc_acq_reset": (C.c_int, [_vp]),
     "gc_acq_set_step_two": (C.c_int, [_vp, C.c_int, C.c_float]),
+    "gc_acq_set_input_format": (C.c_int, [_vp, C.c_int]),
     "gc_acq_dwell_dev": (C.c_int, [_vp, _vp, C.POINTER(AcqResult), _vp]),
     "gc_acq_dwell": (C.c_int, [_vp, _fp, C.POINTER(AcqResult)]),
     "gc_acq_dwell_enqueue": (C.c_int, [_vp, _vp, _vp]),
@@ -433,6 +434,9 @@ class PcpsAcquisition:
         res = (AcqResult * self.n_sats)()
         _check(load_library().gc_acq_dwell(self._h, iq.view(np.float32).ctypes.data_as(_fp), res))
         return list(res)
+
+    def set_input_format(self, iq_format):
+        _check(load_library().gc_acq_set_input_format(self._h, int(iq_format)))
 
     def dwell_dev(self, dev_ptr, stream=None):
         res = (AcqResult * self.n_sats)()

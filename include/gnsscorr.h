@@ -248,6 +248,10 @@ gc_status gc_acq_reset(gc_acq* a);
  * (update_grid_doppler_wipeoffs_step2, :383-390) and restarts the dwell counter; enable == 0 returns to
  * the coarse grid.  Results then follow the step-two Doppler formula (:589-591). */
 gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz);
+/* Sample format of the device input blocks of gc_acq_dwell_dev / gc_acq_dwell_enqueue (default GC_IQ_F32;
+ * GC_IQ_I16 is the block's "cshort" item type, converted like volk_gnsssdr_16ic_convert_32fc does,
+ * pcps_acquisition.cc:676-679).  gc_acq_dwell (host pointer) always takes gr_complex. */
+gc_status gc_acq_set_input_format(gc_acq* a, int iq_format);
 /* One dwell of acquisition_core for every satellite on the same input block
  * (consumed_samples complex).  Non-coherent accumulation across calls like the
  * reference (d_num_noncoherent_integrations_counter).  results: n_sats. */

@@ -186,3 +186,25 @@ def test_all_zero_input_gives_index_zero(gctx, oracle):
     r = acq.dwell(np.zeros(4000, np.complex64))[0]
     assert (r.indext, r.doppler_index, r.mag) == (0, 0, 0.0)
     acq.close()
+
+
+def test_cshort_input_block(gctx, oracle):
+    """item_type cshort: the block converts lv_16sc_t to gr_complex at the head of acquisition_core
+    (pcps_acquisition.cc:676-679); device int16 input must give the float search of the converted block."""
+    import gnsscorr
+    import torch
+    k, x = _kat("gps_l1_ca")
+    q = np.round(x.view(np.float32) * 4000.0).astype(np.int16)
+    xf = q.astype(np.float32).view(np.complex64)
+    c = _conf(k["fs"], 1, 1, 4000.0, 5000, 250)
+    code = oracle.gps_l1_ca_code_sampled(1, k["fs"])
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, **c)
+    acq.set_local_code(0, code)
+    acq.set_input_format(gnsscorr.GC_IQ_I16)
+    d = torch.from_numpy(q).cuda()
+    r = acq.dwell_dev(d.data_ptr())[0]
+    p = oracle.pcps(**c)
+    p.set_local_code(code)
+    _check(r, p.core(xf))
+    assert r.indext == 524
+    acq.close()

@@ -1,0 +1,621 @@
+// trk_closed_loop.hip -- closed-loop DLL/PLL tracking entirely on the GPU.
+//
+// One workgroup per channel runs K code periods back to back: the multicorrelator of
+// trk_device.hpp for the epoch, then -- on one lane -- the per-epoch scalar maths the
+// reference block does on the host between two correlations:
+//   cn0_and_tracking_lock_status   dll_pll_veml_tracking.cc:839-878  (lock_detectors.cc:71-111)
+//   run_dll_pll                    dll_pll_veml_tracking.cc:914-973  (tracking_discriminators.cc:41-128,
+//                                  tracking_loop_filter.cc:74-245, tracking_FLL_PLL_filter.cc:55-133)
+//   update_tracking_vars           dll_pll_veml_tracking.cc:998-1070
+//   pull-in alignment              dll_pll_veml_tracking.cc:1568-1600
+// so that a launch needs no host round trip per millisecond.  The per-epoch
+// record carries what the block puts in Gnss_Synchro and in its binary dump.  Not covered here
+// (host block image only): high-dynamics rate smoothing, telemetry/secondary-code synchronisation.
+#include "gc_internal.h"
+#include "trk_device.hpp"
+#include <cstring>
+#include <vector>
+
+#define LOOP_MAX_CN0 64
+#define LOOP_PI_2 6.283185307179586
+
+// code loop filter without the last integrator (the block constructs it with include_last_integrator = false)
+struct DevLoopFilter
+{
+    float b[4], a[3];
+    int nb, na;
+    float in[4], out[4];
+    int idx;
+};
+
+struct DevPll
+{
+    int order;
+    float w, x, a2, a3, b3, w0p, w0p2, w0p3, w0f, w0f2;
+};
+
+// per-channel persistent state (device memory between launches, LDS during one)
+struct LoopChan
+{
+    gc_loop_conf conf;
+    TrkChan chan;       // iq, code table, taps
+    int n_taps;
+    int state;          // 0 standby, 1 pull-in, 2 tracking
+    int cloop, pull_in_transitory;
+    unsigned long long pos;             // stream index of the next unread sample
+    unsigned long long sample_counter;  // d_sample_counter
+    unsigned long long acq_sample_stamp;
+    double acq_code_phase_samples, acq_carrier_doppler_hz;
+    double carrier_doppler_hz, code_freq_chips;
+    double carrier_phase_step_rad, code_phase_step_chips;
+    double rem_code_phase_samples, rem_code_phase_chips, acc_carrier_phase_rad;
+    float rem_carr_phase_rad;
+    int current_prn_length_samples;
+    double current_correlation_time_s;
+    double carr_phase_error_hz, carr_freq_error_hz, carr_error_filt_hz, code_error_chips, code_error_filt_chips;
+    float2 P_accu_old;
+    DevLoopFilter dll;
+    DevPll pll;
+    float2 prompt_buffer[LOOP_MAX_CN0];
+    int cn0_estimation_counter, carrier_lock_fail_counter;
+    double carrier_lock_test, cn0_db_hz;
+    int lost_lock_events;
+};
+
+// ---- loop filter design: tracking_loop_filter.cc:104-245 (include_last_integrator == false) ----
+static __device__ void dll_design(DevLoopFilter& f, int order, float bw, float T)
+{
+    const float zeta = 1.0 / sqrt(2.0);
+    float g1, g2, g3, wn;
+    f.nb = f.na = 0;
+    switch (order)
+        {
+        case 1:
+            wn = bw * 4.0;
+            g1 = wn;
+            f.b[0] = g1;
+            f.nb = 1;
+            break;
+        case 3:
+            {
+                wn = bw / 0.7845;
+                const float a3 = 1.1, b3 = 2.4;
+                g1 = wn * wn * wn;
+                g2 = a3 * wn * wn;
+                g3 = b3 * wn;
+                f.b[0] = g3 + T / 2.0 * (g2 + T / 2.0 * g1);
+                f.b[1] = g1 * T * T / 2.0 - 2.0 * g3;
+                f.b[2] = g3 + T / 2.0 * (-g2 + T / 2.0 * g1);
+                f.nb = 3;
+                f.a[0] = 2.0f;
+                f.a[1] = -1.0f;
+                f.na = 2;
+                break;
+            }
+        default:
+            wn = bw * (8.0 * zeta) / (4.0 * zeta * zeta + 1.0);
+            g1 = wn * wn;
+            g2 = wn * 2.0 * zeta;
+            f.b[0] = (g1 * T / 2.0 + g2);
+            f.b[1] = g1 * T / 2.0 - g2;
+            f.nb = 2;
+            f.a[0] = 1.0f;
+            f.na = 1;
+            break;
+        }
+}
+
+static __device__ void dll_initialize(DevLoopFilter& f)
+{
+    for (int i = 0; i < 4; i++) f.in[i] = f.out[i] = 0.0f;
+    f.idx = 3;
+}
+
+static __device__ float dll_apply(DevLoopFilter& f, float v)
+{
+    float result = 0.0f;
+    for (int i = 0; i < f.na; ++i) result += f.a[i] * f.out[(f.idx + i) % 4];
+    f.idx--;
+    if (f.idx < 0) f.idx += 4;
+    f.in[f.idx] = v;
+    for (int i = 0; i < f.nb; ++i) result += f.b[i] * f.in[(f.idx + i) % 4];
+    f.out[f.idx] = result;
+    return result;
+}
+
+// ---- carrier loop filter: tracking_FLL_PLL_filter.cc:55-133 ----
+static __device__ void pll_set_params(DevPll& p, float fll_bw_hz, float pll_bw_hz, int order)
+{
+    p.order = order;
+    p.w = p.x = p.a3 = p.b3 = p.w0p3 = p.w0f2 = 0.0f;
+    if (order == 3)
+        {
+            p.b3 = 2.400f;
+            p.a3 = 1.100f;
+            p.a2 = 1.414f;
+            p.w0p = pll_bw_hz / 0.7845;
+            p.w0p2 = p.w0p * p.w0p;
+            p.w0p3 = p.w0p2 * p.w0p;
+            p.w0f = fll_bw_hz / 0.53;
+            p.w0f2 = p.w0f * p.w0f;
+        }
+    else
+        {
+            p.a2 = 1.414f;
+            p.w0p = pll_bw_hz / 0.53;
+            p.w0p2 = p.w0p * p.w0p;
+            p.w0f = fll_bw_hz / 0.25;
+        }
+}
+
+static __device__ float pll_get_carrier_error(DevPll& p, float fll, float pll, float T)
+{
+    float carrier_error_hz;
+    if (p.order == 3)
+        {
+            p.w = p.w + T * (p.w0p3 * pll + p.w0f2 * fll);
+            p.x = p.x + T * (0.5 * p.w + p.a2 * p.w0f * fll + p.a3 * p.w0p2 * pll);
+            carrier_error_hz = 0.5 * p.x + p.b3 * p.w0p * pll;
+        }
+    else
+        {
+            const float w_new = p.w + pll * p.w0p2 * T + fll * p.w0f * T;
+            carrier_error_hz = 0.5 * (w_new + p.w) + p.a2 * p.w0p * pll;
+            p.w = w_new;
+        }
+    return carrier_error_hz;
+}
+
+static __device__ double cabs_d(float2 v) { return (double)hypotf(v.x, v.y); }  // std::abs(gr_complex) is float hypot
+
+// start_tracking (dll_pll_veml_tracking.cc:549-747), loop part
+static __device__ void loop_start(LoopChan& s)
+{
+    const gc_loop_conf& c = s.conf;
+    s.acq_code_phase_samples = c.acq_delay_samples;
+    s.acq_carrier_doppler_hz = c.acq_doppler_hz;
+    s.acq_sample_stamp = c.acq_samplestamp_samples;
+    s.sample_counter = c.sample_counter;
+    s.carrier_doppler_hz = s.acq_carrier_doppler_hz;
+    s.carrier_phase_step_rad = LOOP_PI_2 * s.carrier_doppler_hz / c.fs_in;
+    pll_set_params(s.pll, c.fll_bw_hz, c.pll_bw_hz, c.pll_filter_order);
+    if (s.pll.order == 3)
+        {
+            s.pll.x = 2.0 * (float)s.acq_carrier_doppler_hz;
+            s.pll.w = 0;
+        }
+    else
+        {
+            s.pll.w = (float)s.acq_carrier_doppler_hz;
+            s.pll.x = 0;
+        }
+    dll_design(s.dll, c.dll_filter_order, c.dll_bw_hz, (float)c.code_period_s);
+    dll_initialize(s.dll);
+    s.carrier_lock_fail_counter = 0;
+    s.rem_code_phase_samples = 0.0;
+    s.rem_carr_phase_rad = 0.0f;
+    s.rem_code_phase_chips = 0.0;
+    s.acc_carrier_phase_rad = 0.0;
+    s.cn0_estimation_counter = 0;
+    s.carrier_lock_test = 1.0;
+    s.cn0_db_hz = 0.0;
+    s.current_correlation_time_s = c.code_period_s;
+    s.code_freq_chips = c.code_chip_rate_hz;
+    s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+    s.current_prn_length_samples = (int)c.vector_length;
+    s.P_accu_old = make_float2(0.f, 0.f);
+    s.carr_phase_error_hz = s.carr_freq_error_hz = s.carr_error_filt_hz = s.code_error_chips = s.code_error_filt_chips = 0.0;
+    s.state = 1;
+    s.cloop = 1;
+    s.pull_in_transitory = 1;
+    s.lost_lock_events = 0;
+}
+
+template <int NTAPS>
+__global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
+    gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats)
+{
+    extern __shared__ float lds[];
+    __shared__ LoopChan s;
+    __shared__ gc_epoch_params s_p;
+    __shared__ float2 s_corr[GC_MAX_TAPS];
+    __shared__ int s_go;
+    const int ch = blockIdx.x;
+    const int tid = threadIdx.x;
+    {
+        // cooperative copy of the channel state into LDS
+        const unsigned* src = reinterpret_cast<const unsigned*>(&chans[ch]);
+        unsigned* dst = reinterpret_cast<unsigned*>(&s);
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += TRK_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (s.n_taps != NTAPS) return;
+
+    for (int e = 0; e < n_epochs; e++)
+        {
+            gc_loop_record* rec = &recs[(size_t)ch * n_epochs + e];
+            if (tid == 0)
+                {
+                    const gc_loop_conf& c = s.conf;
+                    int go = 1;
+                    if (s.pull_in_transitory)
+                        {
+                            if (c.pull_in_time_s < (s.sample_counter - s.acq_sample_stamp) / (unsigned long long)(int)c.fs_in) s.pull_in_transitory = 0;
+                        }
+                    if (s.state == 1)
+                        {
+                            // pull-in (:1568-1600): skip samples until the incoming code is aligned with the replica
+                            const long long acq_trk_diff_samples = (long long)s.sample_counter - (long long)s.acq_sample_stamp;
+                            const double delta = (double)acq_trk_diff_samples - s.acq_code_phase_samples;
+                            s.code_freq_chips = c.code_chip_rate_hz;
+                            s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+                            const double T_prn_mod_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
+                            s.acq_code_phase_samples = T_prn_mod_samples - fmod(delta, T_prn_mod_samples);
+                            s.current_prn_length_samples = (int)round(T_prn_mod_samples);
+                            const int samples_offset = (int)round(s.acq_code_phase_samples);
+                            s.acc_carrier_phase_rad -= s.carrier_phase_step_rad * (double)samples_offset;
+                            s.state = 2;
+                            s.sample_counter += samples_offset;
+                            s.pos += samples_offset;
+                        }
+                    if (s.state != 2 || s.pos + c.vector_length > s.chan.n_iq) go = 0;  // standby, or the input block is exhausted
+                    if (go)
+                        {
+                            // do_correlation_step (:886-897): the scalars are narrowed to float exactly there
+                            const float spc = (float)c.code_samples_per_chip;
+                            const float rem_carr = s.rem_carr_phase_rad;
+                            const float pstep = (float)s.carrier_phase_step_rad;
+                            s_p.sample_offset = s.pos;
+                            s_p.phase0_re = cosf(rem_carr);
+                            s_p.phase0_im = -sinf(rem_carr);
+                            s_p.phase_inc_re = cosf(pstep);
+                            s_p.phase_inc_im = -sinf(pstep);
+                            s_p.phase_rate_re = 1.0f;
+                            s_p.phase_rate_im = 0.0f;
+                            s_p.rem_code_phase_chips = (float)s.rem_code_phase_chips * spc;
+                            s_p.code_phase_step_chips = (float)s.code_phase_step_chips * spc;
+                            s_p.code_phase_rate_step_chips = 0.0f;
+                            s_p.n_samples = (int)c.vector_length;
+                        }
+                    else
+                        {
+                            // nothing to correlate: an invalid record marks the epoch (records are written in
+                            // place, field by field: no stack copies)
+                            unsigned* w = reinterpret_cast<unsigned*>(rec);
+                            for (unsigned i = 0; i < sizeof(gc_loop_record) / 4; i++) w[i] = 0u;
+                            rec->state = s.state;
+                            rec->sample_counter = s.sample_counter;
+                        }
+                    s_go = go;
+                }
+            __syncthreads();
+            if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
+
+            const float2 r = trk_epoch<NTAPS, false, false, GC_IQ_F32>(s.chan, s_p, 0, 1, lds_table_floats, lds);
+            if (tid < NTAPS) s_corr[tid] = r;
+            __syncthreads();
+
+            if (tid == 0)
+                {
+                    const gc_loop_conf& c = s.conf;
+                    const bool veml = NTAPS == 5;
+                    const float2 VE = veml ? s_corr[0] : make_float2(0.f, 0.f);
+                    const float2 VL = veml ? s_corr[4] : make_float2(0.f, 0.f);
+                    const float2 E = s_corr[veml ? 1 : 0], P = s_corr[veml ? 2 : 1], L = s_corr[veml ? 3 : 2];
+                    {
+                        unsigned* w = reinterpret_cast<unsigned*>(rec);
+                        for (unsigned i = 0; i < sizeof(gc_loop_record) / 4; i++) w[i] = 0u;
+                    }
+                    for (int t = 0; t < NTAPS; t++)
+                        {
+                            rec->corr[2 * t] = s_corr[t].x;
+                            rec->corr[2 * t + 1] = s_corr[t].y;
+                        }
+                    int valid = 0;
+                    // ---- cn0_and_tracking_lock_status (:839-878) ----
+                    bool locked = true;
+                    if (s.cn0_estimation_counter < c.cn0_samples)
+                        {
+                            s.prompt_buffer[s.cn0_estimation_counter] = P;
+                            s.cn0_estimation_counter++;
+                        }
+                    else
+                        {
+                            s.cn0_estimation_counter = 0;
+                            double Psig = 0.0, Ptot = 0.0;
+                            float sum_I = 0.f, sum_Q = 0.f;
+                            for (int i = 0; i < c.cn0_samples; i++)
+                                {
+                                    const float2 v = s.prompt_buffer[i];
+                                    Psig += fabs((double)v.x);
+                                    Ptot += (double)v.y * (double)v.y + (double)v.x * (double)v.x;
+                                    sum_I += v.x;
+                                    sum_Q += v.y;
+                                }
+                            Psig /= (double)c.cn0_samples;
+                            Psig = Psig * Psig;
+                            Ptot /= (double)c.cn0_samples;
+                            const double SNR = Psig / (Ptot - Psig);
+                            s.cn0_db_hz = (double)(float)(10.0 * log10(SNR) - 10.0 * log10(c.code_period_s));
+                            const float NBP = sum_I * sum_I + sum_Q * sum_Q, NBD = sum_I * sum_I - sum_Q * sum_Q;
+                            s.carrier_lock_test = (double)(NBD / NBP);
+                            if (!s.pull_in_transitory)
+                                {
+                                    if (s.carrier_lock_test < c.carrier_lock_th || s.cn0_db_hz < c.cn0_min)
+                                        s.carrier_lock_fail_counter++;
+                                    else if (s.carrier_lock_fail_counter > 0)
+                                        s.carrier_lock_fail_counter--;
+                                }
+                            if (s.carrier_lock_fail_counter > c.max_lock_fail)
+                                {
+                                    s.lost_lock_events++;  // message 3 on the "events" port
+                                    s.carrier_lock_fail_counter = 0;
+                                    locked = false;
+                                }
+                        }
+                    if (!locked)
+                        {
+                            // clear_tracking_vars (:976-995) + standby
+                            s.P_accu_old = make_float2(0.f, 0.f);
+                            s.carr_phase_error_hz = s.carr_freq_error_hz = s.carr_error_filt_hz = 0.0;
+                            s.code_error_chips = s.code_error_filt_chips = 0.0;
+                            s.state = 0;
+                        }
+                    else
+                        {
+                            // ---- run_dll_pll (:914-973) ----
+                            if (s.cloop)
+                                s.carr_phase_error_hz = ((P.x != 0.0f) ? (double)atanf(P.y / P.x) : 0.0) / LOOP_PI_2;
+                            else
+                                s.carr_phase_error_hz = (double)atan2f(P.y, P.x) / LOOP_PI_2;
+                            if ((s.pull_in_transitory && c.enable_fll_pull_in) || c.enable_fll_steady_state)
+                                {
+                                    const double dot = s.P_accu_old.x * P.x + s.P_accu_old.y * P.y;
+                                    const double cross = s.P_accu_old.x * P.y - P.x * s.P_accu_old.y;
+                                    s.carr_freq_error_hz = atan2(cross, dot) / (s.current_correlation_time_s - 0.0) / LOOP_PI_2;
+                                    s.P_accu_old = P;
+                                    if (s.pull_in_transitory && c.enable_fll_pull_in)
+                                        s.carr_error_filt_hz = pll_get_carrier_error(s.pll, (float)s.carr_freq_error_hz, 0.0f, (float)s.current_correlation_time_s);
+                                    else
+                                        s.carr_error_filt_hz = pll_get_carrier_error(s.pll, (float)s.carr_freq_error_hz, (float)s.carr_phase_error_hz, (float)s.current_correlation_time_s);
+                                }
+                            else
+                                s.carr_error_filt_hz = pll_get_carrier_error(s.pll, 0.0f, (float)s.carr_phase_error_hz, (float)s.current_correlation_time_s);
+                            s.carrier_doppler_hz = s.carr_error_filt_hz;
+                            if (veml)
+                                {
+                                    const double pe = sqrt((double)(VE.x * VE.x + VE.y * VE.y) + (double)(E.x * E.x + E.y * E.y));
+                                    const double pl = sqrt((double)(VL.x * VL.x + VL.y * VL.y) + (double)(L.x * L.x + L.y * L.y));
+                                    s.code_error_chips = (pe + pl == 0.0) ? 0.0 : (pe - pl) / (pe + pl);
+                                }
+                            else
+                                {
+                                    const double pe = cabs_d(E), pl = cabs_d(L);
+                                    s.code_error_chips = (pe + pl == 0.0) ? 0.0 : 0.5 * (pe - pl) / (pe + pl);
+                                }
+                            s.code_error_filt_chips = dll_apply(s.dll, (float)s.code_error_chips);
+                            s.code_freq_chips = (1.0 + (s.carrier_doppler_hz / c.signal_carrier_freq_hz)) * c.code_chip_rate_hz - s.code_error_filt_chips;
+                            // ---- update_tracking_vars (:998-1070), no high-dynamics terms ----
+                            const double T_prn_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
+                            const double K_blk_samples = T_prn_samples + s.rem_code_phase_samples;
+                            s.current_prn_length_samples = (int)floor(K_blk_samples);
+                            s.carrier_phase_step_rad = LOOP_PI_2 * s.carrier_doppler_hz / c.fs_in;
+                            const double n = (double)s.current_prn_length_samples;
+                            s.rem_carr_phase_rad += (float)(s.carrier_phase_step_rad * n);
+                            s.rem_carr_phase_rad = fmodf(s.rem_carr_phase_rad, (float)LOOP_PI_2);
+                            s.acc_carrier_phase_rad -= s.carrier_phase_step_rad * n;
+                            s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+                            s.rem_code_phase_samples = K_blk_samples - n;
+                            s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
+                            valid = 1;
+                        }
+                    s.sample_counter += (unsigned long long)s.current_prn_length_samples;
+                    s.pos += (unsigned long long)s.current_prn_length_samples;
+                    rec->sample_counter = s.sample_counter;
+                    rec->acc_carrier_phase_rad = s.acc_carrier_phase_rad;
+                    rec->rem_code_phase_samples = s.rem_code_phase_samples;
+                    rec->carrier_doppler_hz = (float)s.carrier_doppler_hz;
+                    rec->code_freq_chips = (float)s.code_freq_chips;
+                    rec->carr_phase_error_hz = (float)s.carr_phase_error_hz;
+                    rec->carr_error_filt_hz = (float)s.carr_error_filt_hz;
+                    rec->code_error_chips = (float)s.code_error_chips;
+                    rec->code_error_filt_chips = (float)s.code_error_filt_chips;
+                    rec->cn0_db_hz = (float)s.cn0_db_hz;
+                    rec->carrier_lock_test = (float)s.carrier_lock_test;
+                    rec->state = s.state;
+                    rec->valid = valid;
+                    rec->current_prn_length_samples = s.current_prn_length_samples;
+                }
+            // the next iteration's barrier orders these writes before any other thread reads s / s_p again
+        }
+    __syncthreads();
+    {
+        unsigned* dst = reinterpret_cast<unsigned*>(&chans[ch]);
+        const unsigned* src = reinterpret_cast<const unsigned*>(&s);
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += TRK_THREADS) dst[i] = src[i];
+    }
+}
+
+__global__ void trk_loop_start_kernel(LoopChan* chans, int ch)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) loop_start(chans[ch]);
+}
+
+// -----------------------------------------------------------------------------
+// host API
+// -----------------------------------------------------------------------------
+struct gc_trk_loop
+{
+    gc_ctx* ctx = nullptr;
+    int n_channels = 0, max_code_len = 0, n_taps = 0;
+    LoopChan* d_chans = nullptr;
+    float* d_codes = nullptr;
+    gc_loop_record* d_recs = nullptr;
+    size_t recs_cap = 0;
+    std::vector<char> started;
+    std::vector<const void*> iq;
+    std::vector<unsigned long long> n_iq;
+};
+
+extern "C" {
+
+gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, gc_trk_loop** out)
+{
+    GC_REQUIRE(ctx && out, "gc_trk_loop_create: NULL argument");
+    *out = nullptr;
+    GC_REQUIRE(n_channels > 0, "gc_trk_loop_create: n_channels must be > 0");
+    GC_REQUIRE(max_code_length > 0 && max_code_length + 64 <= 16000, "gc_trk_loop_create: max_code_length must be in 1..%d", 16000 - 64);
+    gc_device_guard g(ctx->device);
+    gc_trk_loop* l = new gc_trk_loop();
+    l->ctx = ctx;
+    l->n_channels = n_channels;
+    l->max_code_len = max_code_length;
+    hipError_t e1 = hipMalloc(&l->d_chans, sizeof(LoopChan) * n_channels);
+    hipError_t e2 = hipMalloc(&l->d_codes, sizeof(float) * (size_t)n_channels * max_code_length);
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        {
+            (void)hipFree(l->d_chans);
+            (void)hipFree(l->d_codes);
+            delete l;
+            return gc_fail(GC_ERR_HIP, "gc_trk_loop_create: hipMalloc failed");
+        }
+    (void)hipMemset(l->d_chans, 0, sizeof(LoopChan) * n_channels);
+    l->started.assign(n_channels, 0);
+    l->iq.assign(n_channels, nullptr);
+    l->n_iq.assign(n_channels, 0);
+    *out = l;
+    return GC_OK;
+}
+
+gc_status gc_trk_loop_destroy(gc_trk_loop* l)
+{
+    if (!l) return GC_OK;
+    gc_device_guard g(l->ctx->device);
+    (void)hipStreamSynchronize(l->ctx->stream);
+    (void)hipFree(l->d_chans);
+    (void)hipFree(l->d_codes);
+    (void)hipFree(l->d_recs);
+    delete l;
+    return GC_OK;
+}
+
+gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, uint64_t n_samples)
+{
+    GC_REQUIRE(l && dev_iq, "gc_trk_loop_set_input_dev: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_set_input_dev: channel %d out of range", ch);
+    GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) & 7) == 0, "gc_trk_loop_set_input_dev: IQ pointer must be 8-byte aligned");
+    gc_device_guard g(l->ctx->device);
+    l->iq[ch] = dev_iq;
+    l->n_iq[ch] = n_samples;
+    if (l->started[ch])
+        {
+            // a running channel keeps its state; only the input block changes (stream position restarts at 0)
+            GC_HIP(hipStreamSynchronize(l->ctx->stream));
+            LoopChan h;
+            GC_HIP(hipMemcpy(&h, l->d_chans + ch, sizeof h, hipMemcpyDeviceToHost));
+            h.chan.iq = dev_iq;
+            h.chan.n_iq = n_samples;
+            h.pos = 0;
+            GC_HIP(hipMemcpy(l->d_chans + ch, &h, sizeof h, hipMemcpyHostToDevice));
+        }
+    return GC_OK;
+}
+
+gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, const float* code, int code_length)
+{
+    GC_REQUIRE(l && conf && code, "gc_trk_loop_start: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_start: channel %d out of range", ch);
+    GC_REQUIRE(code_length > 0 && code_length <= l->max_code_len, "gc_trk_loop_start: code_length %d not in 1..%d", code_length, l->max_code_len);
+    GC_REQUIRE(l->iq[ch] != nullptr, "gc_trk_loop_start: channel %d has no input (gc_trk_loop_set_input_dev)", ch);
+    GC_REQUIRE(conf->cn0_samples >= 1 && conf->cn0_samples <= LOOP_MAX_CN0, "gc_trk_loop_start: cn0_samples must be in 1..%d", LOOP_MAX_CN0);
+    GC_REQUIRE(conf->vector_length > 0 && conf->fs_in > 0 && conf->code_chip_rate_hz > 0, "gc_trk_loop_start: bad signal description");
+    GC_REQUIRE((uint32_t)code_length == conf->code_length_chips * conf->code_samples_per_chip,
+        "gc_trk_loop_start: code_length %d != code_length_chips * code_samples_per_chip", code_length);
+    const int n_taps = conf->veml ? 5 : 3;
+    if (l->n_taps == 0) l->n_taps = n_taps;
+    GC_REQUIRE(l->n_taps == n_taps, "gc_trk_loop_start: all channels of one loop engine use the same tap count (%d)", l->n_taps);
+    gc_device_guard g(l->ctx->device);
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    hipStream_t st = l->ctx->stream;
+    GC_HIP(hipStreamSynchronize(st));
+    GC_HIP(hipMemcpy(l->d_codes + (size_t)ch * l->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
+    LoopChan h;
+    std::memset(&h, 0, sizeof h);
+    h.conf = *conf;
+    h.chan.iq = l->iq[ch];
+    h.chan.n_iq = l->n_iq[ch];
+    h.chan.code = l->d_codes + (size_t)ch * l->max_code_len;
+    h.chan.code_len = code_length;
+    h.n_taps = n_taps;
+    // tap shifts in code samples (dll_pll_veml_tracking.cc:372-390, :720-732)
+    const float spc = (float)conf->code_samples_per_chip;
+    if (conf->veml)
+        {
+            h.chan.shifts[0] = -conf->very_early_late_space_chips * spc;
+            h.chan.shifts[1] = -conf->early_late_space_chips * spc;
+            h.chan.shifts[2] = 0.0f;
+            h.chan.shifts[3] = conf->early_late_space_chips * spc;
+            h.chan.shifts[4] = conf->very_early_late_space_chips * spc;
+        }
+    else
+        {
+            h.chan.shifts[0] = -conf->early_late_space_chips * spc;
+            h.chan.shifts[1] = 0.0f;
+            h.chan.shifts[2] = conf->early_late_space_chips * spc;
+        }
+    h.pos = 0;
+    GC_HIP(hipMemcpy(l->d_chans + ch, &h, sizeof h, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(trk_loop_start_kernel, dim3(1), dim3(64), 0, st, l->d_chans, ch);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipStreamSynchronize(st));
+    l->started[ch] = 1;
+    return GC_OK;
+}
+
+static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, hipStream_t st)
+{
+    for (int i = 0; i < l->n_channels; i++)
+        if (!l->started[i]) return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: channel %d has not been started (gc_trk_loop_start)", i);
+    const int lds_table_floats = l->max_code_len + 64;
+    const size_t lds_bytes = (size_t)(TRK_HDR_FLOATS + lds_table_floats) * sizeof(float);
+    if (l->n_taps == 5)
+        hipLaunchKernelGGL((trk_closed_loop_kernel<5>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats);
+    else
+        hipLaunchKernelGGL((trk_closed_loop_kernel<3>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+gc_status gc_trk_loop_run_dev(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, void* stream)
+{
+    GC_REQUIRE(l && dev_records, "gc_trk_loop_run_dev: NULL argument");
+    GC_REQUIRE(n_epochs > 0, "gc_trk_loop_run_dev: n_epochs must be > 0");
+    gc_device_guard g(l->ctx->device);
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    return loop_launch(l, n_epochs, dev_records, gc_pick_stream(l->ctx, stream));
+}
+
+gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_records)
+{
+    GC_REQUIRE(l && host_records, "gc_trk_loop_run: NULL argument");
+    GC_REQUIRE(n_epochs > 0, "gc_trk_loop_run: n_epochs must be > 0");
+    gc_device_guard g(l->ctx->device);
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    hipStream_t st = l->ctx->stream;
+    const size_t n = (size_t)l->n_channels * n_epochs;
+    if (n > l->recs_cap)
+        {
+            (void)hipFree(l->d_recs);
+            l->d_recs = nullptr;
+            l->recs_cap = 0;
+            GC_HIP(hipMalloc(&l->d_recs, n * sizeof(gc_loop_record)));
+            l->recs_cap = n;
+        }
+    gc_status s = loop_launch(l, n_epochs, l->d_recs, st);
+    if (s != GC_OK) return s;
+    GC_HIP(hipMemcpyAsync(host_records, l->d_recs, n * sizeof(gc_loop_record), hipMemcpyDeviceToHost, st));
+    GC_HIP(hipStreamSynchronize(st));
+    return GC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,517 @@
+// trk_device.hpp -- device-side code of the tracking multicorrelator (shared by the batched open-loop
+// kernel, trk_kernels.hip, and the closed-loop kernel, trk_closed_loop.hip).  See trk_kernels.hip for
+// the reference citations and the design notes.
+#ifndef TRK_DEVICE_HPP
+#define TRK_DEVICE_HPP
+#include "gnsscorr.h"
+#include "trk_kernels.h"
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#define TRK_THREADS 256
+#define TRK_CHUNK 512  // samples per workgroup iteration (2 per lane)
+#define TRK_HDR_FLOATS 64
+#define TRK_RESYNC 64  // iterations between exact re-evaluations of the carrier phase
+#ifndef TRK_PF
+#define TRK_PF 2  // chunks prefetched ahead of the one being processed (16-byte loads in flight per lane)
+#endif
+#ifndef TRK_NT
+#define TRK_NT 0  // 1: nontemporal IQ loads
+#endif
+
+static __device__ __forceinline__ int posmod(int i, int L)
+{
+    int r = i % L;
+    return r < 0 ? r + L : r;
+}
+
+// chip index before wrapping, generic resampler order: ((step*n) + shift) - rem
+static __device__ __forceinline__ int chip_index(float step, float nf, float shift, float rem)
+{
+    float a = step * nf;
+    float b = a + shift;
+    float c = b - rem;
+    return (int)floorf(c);
+}
+
+// high-dynamics first tap: (((step*n) + rate*(float)(n*n)) + shift0) - rem, n*n in uint32
+static __device__ __forceinline__ int chip_index_hd(float step, float rate, unsigned n, float shift0, float rem)
+{
+    float a = step * (float)n;
+    float r = rate * (float)(n * n);
+    float b = a + r;
+    float c = b + shift0;
+    float d = c - rem;
+    return (int)floorf(d);
+}
+
+// sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic);
+// the total ends in lane 63
+static __device__ __forceinline__ float wave_sum(float v)
+{
+#define GC_DPP_ADD(ctrl, row_mask, bank_mask)                                                                    \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, bank_mask, false))
+    GC_DPP_ADD(0x111, 0xf, 0xf);  // row_shr:1
+    GC_DPP_ADD(0x112, 0xf, 0xf);  // row_shr:2
+    GC_DPP_ADD(0x114, 0xf, 0xe);  // row_shr:4
+    GC_DPP_ADD(0x118, 0xf, 0xc);  // row_shr:8  -> lane 15 of every row holds the row sum
+    GC_DPP_ADD(0x142, 0xa, 0xf);  // row_bcast:15
+    GC_DPP_ADD(0x143, 0xc, 0xf);  // row_bcast:31 -> lane 63 holds the wave sum
+#undef GC_DPP_ADD
+    return v;
+}
+
+// exact carrier rotator for sample n: exp(j*(theta0 + n*dtheta [+ e(n)*drate]))
+template <bool HDC>
+static __device__ __forceinline__ void carrier_at(int n, double theta0, double dtheta, double drate,
+    float& zr, float& zi)
+{
+    double th = fma((double)n, dtheta, theta0);
+    if (HDC)
+        {
+            // the reference applies cpowf(rate, (n-1)^2) to sample n (n >= 1), with
+            // the square taken in unsigned 32-bit arithmetic and converted to float
+            unsigned m = (n > 0) ? (unsigned)(n - 1) : 0u;
+            float e = (float)(m * m);
+            th = fma((double)e, drate, th);
+        }
+    const double inv2pi = 0.15915494309189533577;
+    const double twopi = 6.283185307179586477;
+    double t = th * inv2pi;
+    t -= rint(t);
+    float ang = (float)(t * twopi);
+    sincosf(ang, &zi, &zr);
+}
+
+#define GC_GLOBAL __attribute__((address_space(1)))
+// native vector types: loads through an address-space-qualified pointer need plain (non-class) types
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef signed char i8x2 __attribute__((ext_vector_type(2)));
+typedef signed char i8x4 __attribute__((ext_vector_type(4)));
+
+// IQ sample formats in HBM (gc_iq_format).  Integer samples are converted with a plain cast, like the
+// reference's volk_gnsssdr_16ic_convert_32fc / interleaved-byte adapters do before the float correlators,
+// so the arithmetic downstream is identical; only the bytes per sample change (8 / 4 / 2).
+template <int FMT>
+struct IqFmt;
+template <>
+struct IqFmt<GC_IQ_F32>
+{
+    typedef f32x2 elem;
+    typedef f32x4 pair;
+    static __device__ __forceinline__ f32x4 cvt(pair v) { return v; }
+    static __device__ __forceinline__ f32x2 cvt1(elem v) { return v; }
+};
+template <>
+struct IqFmt<GC_IQ_I16>
+{
+    typedef i16x2 elem;
+    typedef i16x4 pair;
+    static __device__ __forceinline__ f32x4 cvt(pair v) { return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
+    static __device__ __forceinline__ f32x2 cvt1(elem v) { return f32x2{(float)v.x, (float)v.y}; }
+};
+template <>
+struct IqFmt<GC_IQ_I8>
+{
+    typedef i8x2 elem;
+    typedef i8x4 pair;
+    static __device__ __forceinline__ f32x4 cvt(pair v) { return f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
+    static __device__ __forceinline__ f32x2 cvt1(elem v) { return f32x2{(float)v.x, (float)v.y}; }
+};
+
+// (int)floorf(x) in one instruction (v_floor_f32 + v_cvt_i32_f32 otherwise)
+static __device__ __forceinline__ int floor_to_int(float x)
+{
+    int i;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+    return i;
+}
+
+// Main loop over the chunks [c0, c1) of one (channel, epoch, slice).
+//   WINDOWED: table[] holds code[(lo + k) mod L], indices need no wrap
+//   else    : table[] holds code[0..L), indices are wrapped with the reference's modulo
+template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT>
+static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
+    int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
+    const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
+    float (&accr)[NTAPS], float (&acci)[NTAPS])
+{
+    const int tid = threadIdx.x;
+    const float* tl = table - lo;  // windowed lookups index with the unwrapped chip number
+
+    // per-chunk advance of the two per-lane rotators: exp(j*TRK_CHUNK*dtheta)
+    float wr = 1.0f, wi = 0.0f;
+    if (!HDC)
+        {
+            double t = (double)TRK_CHUNK * dtheta * 0.15915494309189533577;
+            t -= rint(t);
+            sincosf((float)(t * 6.283185307179586477), &wi, &wr);
+        }
+    // second sample of the lane's pair: one more step of the carrier
+    float w1r = 1.0f, w1i = 0.0f;
+    if (!HDC)
+        {
+            double t = dtheta * 0.15915494309189533577;
+            t -= rint(t);
+            sincosf((float)(t * 6.283185307179586477), &w1i, &w1r);
+        }
+    float z0r = 1.0f, z0i = 0.0f, z1r = 1.0f, z1i = 0.0f;
+
+    // A chunk is "full" when every lane's two samples lie inside the window: plain 16-byte loads, no
+    // masks, no clamps.  Only the first chunk (odd-aligned window) and the last one can be ragged; they
+    // are processed outside the pipelined interior loop.
+    auto chunk_is_full = [&](int c) { return (c > 0 || a == 0) && (c + 1) * TRK_CHUNK <= V; };
+    auto load_full = [&](int c) -> f32x4 {
+        // uniform chunk base + constant per-lane offset: SGPR-base global loads
+        typedef typename IqFmt<FMT>::pair pair_t;
+        const GC_GLOBAL char* p = reinterpret_cast<const GC_GLOBAL char*>(base) + (size_t)c * (TRK_CHUNK / 2 * sizeof(pair_t)) + tid * sizeof(pair_t);
+#if TRK_NT
+        return IqFmt<FMT>::cvt(__builtin_nontemporal_load(reinterpret_cast<const GC_GLOBAL pair_t*>(p)));
+#else
+        return IqFmt<FMT>::cvt(*reinterpret_cast<const GC_GLOBAL pair_t*>(p));
+#endif
+    };
+    auto load_masked = [&](int c) -> f32x4 {
+        const int v = c * TRK_CHUNK + tid * 2;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (v >= a && v < V)
+            {
+                f32x2 s = IqFmt<FMT>::cvt1(base[v]);
+                x.x = s.x;
+                x.y = s.y;
+            }
+        if (v + 1 >= a && v + 1 < V)
+            {
+                f32x2 s = IqFmt<FMT>::cvt1(base[v + 1]);
+                x.z = s.x;
+                x.w = s.y;
+            }
+        return x;
+    };
+    // exact re-evaluation of both rotators (every TRK_RESYNC chunks)
+    auto resync = [&](int c) {
+        if (!HDC)
+            {
+                const int v = c * TRK_CHUNK + tid * 2;
+                carrier_at<false>(v - a, theta0, dtheta, 0.0, z0r, z0i);
+                z1r = fmaf(z0r, w1r, -(z0i * w1i));
+                z1i = fmaf(z0r, w1i, z0i * w1r);
+            }
+    };
+    // one chunk of work, then one step of the rotators
+    auto process = [&](auto full_tag, int c, const f32x4 xc) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int v = c * TRK_CHUNK + tid * 2;
+        int n0 = v - a, n1 = v + 1 - a;
+        if (!FULL)
+            {
+                // masked lanes carry zero input; keep their sample number inside the window
+                n0 = min(max(n0, 0), N - 1);
+                n1 = min(max(n1, 0), N - 1);
+            }
+        if (HDC)
+            {
+                carrier_at<true>(n0, theta0, dtheta, drate, z0r, z0i);
+                carrier_at<true>(n1, theta0, dtheta, drate, z1r, z1i);
+                // the reference's phase_doppler is never renormalised: its modulus drifts as
+                // |phase_inc|^n; samples with n % 256 == 0 are renormalised before use
+                float g0 = (n0 & 255) ? fmaf((float)n0, lnmod, 1.0f) : 1.0f;
+                float g1 = (n1 & 255) ? fmaf((float)n1, lnmod, 1.0f) : 1.0f;
+                z0r *= g0;
+                z0i *= g0;
+                z1r *= g1;
+                z1i *= g1;
+            }
+        // ---- wipe-off: y = x * z ----
+        const float y0r = fmaf(xc.x, z0r, -(xc.y * z0i));
+        const float y0i = fmaf(xc.x, z0i, xc.y * z0r);
+        const float y1r = fmaf(xc.z, z1r, -(xc.w * z1i));
+        const float y1i = fmaf(xc.z, z1i, xc.w * z1r);
+        // ---- code NCO + E/P/L accumulation ----
+        if (HDR)
+            {
+#pragma unroll
+                for (int t = 0; t < NTAPS; t++)
+                    {
+                        // tap t at sample n reads tap 0 at sample (n + delay) wrapped at N (…:100-106)
+                        int m0 = n0 + tap_delay[t];
+                        int m1 = n1 + tap_delay[t];
+                        if (t > 0)
+                            {
+                                m0 = (m0 >= N) ? m0 - N : m0;
+                                m1 = (m1 >= N) ? m1 - N : m1;
+                                m0 = min(max(m0, 0), N - 1);
+                                m1 = min(max(m1, 0), N - 1);
+                            }
+                        const int i0 = chip_index_hd(step, rate, (unsigned)m0, shifts[0], rem);
+                        const int i1 = chip_index_hd(step, rate, (unsigned)m1, shifts[0], rem);
+                        const float cv0 = WINDOWED ? tl[i0] : table[posmod(i0, L)];
+                        const float cv1 = WINDOWED ? tl[i1] : table[posmod(i1, L)];
+                        accr[t] = fmaf(y0r, cv0, accr[t]);
+                        acci[t] = fmaf(y0i, cv0, acci[t]);
+                        accr[t] = fmaf(y1r, cv1, accr[t]);
+                        acci[t] = fmaf(y1i, cv1, acci[t]);
+                    }
+            }
+        else
+            {
+                const float s0 = step * (float)n0, s1 = step * (float)n1;
+#pragma unroll
+                for (int t = 0; t < NTAPS; t++)
+                    {
+                        const int i0 = floor_to_int((s0 + shifts[t]) - rem);
+                        const int i1 = floor_to_int((s1 + shifts[t]) - rem);
+                        const float cv0 = WINDOWED ? tl[i0] : table[posmod(i0, L)];
+                        const float cv1 = WINDOWED ? tl[i1] : table[posmod(i1, L)];
+                        accr[t] = fmaf(y0r, cv0, accr[t]);
+                        acci[t] = fmaf(y0i, cv0, acci[t]);
+                        accr[t] = fmaf(y1r, cv1, accr[t]);
+                        acci[t] = fmaf(y1i, cv1, acci[t]);
+                    }
+            }
+        if (!HDC)
+            {
+                // advance both rotators by one chunk
+                const float t0 = fmaf(z0r, wr, -(z0i * wi));
+                z0i = fmaf(z0r, wi, z0i * wr);
+                z0r = t0;
+                const float t1 = fmaf(z1r, wr, -(z1i * wi));
+                z1i = fmaf(z1r, wi, z1i * wr);
+                z1r = t1;
+            }
+    };
+
+    if (c0 >= c1) return;
+    int c = c0;
+    // ---- ragged head (at most one chunk) ----
+    if (!chunk_is_full(c))
+        {
+            resync(c);
+            process(std::false_type{}, c, load_masked(c));
+            ++c;
+        }
+    // ---- interior: full chunks, TRK_PF loads in flight ahead of the chunk being processed ----
+    const int cf1 = (c < c1 && !chunk_is_full(c1 - 1)) ? c1 - 1 : c1;
+    if (c < cf1)
+        {
+            // two loads in flight per lane; the loop is unrolled by two so that the buffers keep their
+            // registers (a rotating queue would have to wait for the youngest load to move it)
+            // prefetches past the end re-read the last full chunk (in bounds, value unused): no branch
+            // in the loop body, so the compiler can wait with vmcnt(1) and keep one load in flight
+            const int clast = cf1 - 1;
+            f32x4 x0 = load_full(c);
+            f32x4 x1 = load_full(min(c + 1, clast));
+            while (c < cf1)
+                {
+                    if ((c - c0) % TRK_RESYNC == 0) resync(c);
+                    const int gend = min(cf1, c0 + ((c - c0) / TRK_RESYNC + 1) * TRK_RESYNC);
+                    while (c + 2 <= gend)
+                        {
+                            const f32x4 xa = x0;
+                            x0 = load_full(min(c + 2, clast));
+                            process(std::true_type{}, c, xa);
+                            const f32x4 xb = x1;
+                            x1 = load_full(min(c + 3, clast));
+                            process(std::true_type{}, c + 1, xb);
+                            c += 2;
+                        }
+                    if (c < gend)
+                        {
+                            // odd chunk left in this group: the buffers swap roles
+                            const f32x4 xa = x0;
+                            x0 = x1;
+                            x1 = load_full(min(c + 2, clast));
+                            process(std::true_type{}, c, xa);
+                            ++c;
+                        }
+                }
+        }
+    // ---- ragged tail (at most one chunk) ----
+    if (c < c1)
+        {
+            if ((c - c0) % TRK_RESYNC == 0) resync(c);
+            process(std::false_type{}, c, load_masked(c));
+        }
+}
+
+// One (channel, epoch, slice): builds the LDS code window, streams the IQ window, reduces the tap sums.
+// Every thread of the 256-thread workgroup must call it; the sum of tap `tid` is returned to the threads
+// with tid < NTAPS (others get 0).  lds: TRK_HDR_FLOATS + lds_table_floats floats of dynamic LDS.
+template <int NTAPS, bool HDR, bool HDC, int FMT>
+static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
+    int lds_table_floats, float* lds)
+{
+    // lds[0..63]: header (wave partials); lds[64..]: code window
+    float* table = lds + TRK_HDR_FLOATS;
+    const int tid = threadIdx.x;
+    const int N = p.n_samples;
+    const int L = cd.code_len;
+
+    typedef typename IqFmt<FMT>::elem elem_t;
+    const elem_t* iq = static_cast<const elem_t*>(cd.iq) + p.sample_offset;
+    const int a = (int)((reinterpret_cast<uintptr_t>(iq) / sizeof(elem_t)) & 1);  // 1: window starts on the odd half of a sample pair
+    // pair-aligned; sample n lives at base[n + a].  IQ lives in HBM: global (not flat) loads
+    const GC_GLOBAL elem_t* base = (const GC_GLOBAL elem_t*)(iq - a);
+    const int V = N + a;
+    const int n_chunks = (V + TRK_CHUNK - 1) / TRK_CHUNK;
+    const int cps = (n_chunks + n_slices - 1) / n_slices;
+    const int c0 = slice * cps;
+    const int c1 = min(n_chunks, c0 + cps);
+
+    const float step = p.code_phase_step_chips;
+    const float rem = p.rem_code_phase_chips;
+    const float rate = p.code_phase_rate_step_chips;
+
+    float shifts[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; t++) shifts[t] = cd.shifts[t];
+
+    // high-dynamics resampler: taps >= 1 are tap 0 delayed by whole samples
+    int tap_delay[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; t++) tap_delay[t] = 0;
+    if (HDR)
+        {
+            unsigned acc = 0;
+#pragma unroll
+            for (int t = 1; t < NTAPS; t++)
+                {
+                    acc += (unsigned)(int)rintf((shifts[t] - shifts[t - 1]) / step);
+                    tap_delay[t] = (int)acc;
+                }
+        }
+
+    // ---- carrier angles ----
+    // theta0 only needs ~1e-7 rad (it is a constant rotation of the result): float atan2.  The
+    // per-sample increment is multiplied by up to 1e5 samples: float64, from the series of atan(t),
+    // t = im/re, whenever |t| is small (any Doppler below ~2 % of the sampling rate), atan2 otherwise.
+    double theta0, dtheta, drate = 0.0;
+    float lnmod = 0.0f;
+    {
+        theta0 = (double)atan2f(p.phase0_im, p.phase0_re);
+        auto small_angle = [](float im, float re) -> double {
+            const double t = (double)im / (double)re;
+            if (re > 0.0f && fabs(t) < 0.03)
+                {
+                    const double t2 = t * t;
+                    return t * (1.0 + t2 * (-1.0 / 3.0 + t2 * (0.2 + t2 * (-1.0 / 7.0 + t2 * (1.0 / 9.0)))));
+                }
+            return atan2((double)im, (double)re);
+        };
+        dtheta = small_angle(p.phase_inc_im, p.phase_inc_re);
+        if (HDC)
+            {
+                drate = small_angle(p.phase_rate_im, p.phase_rate_re);
+                lnmod = (float)(0.5 * log((double)p.phase_inc_re * p.phase_inc_re + (double)p.phase_inc_im * p.phase_inc_im));
+            }
+    }
+
+    // ---- code window in LDS ----
+    // Sample numbers this slice touches (clamped lanes included): [n_lo, n_hi].
+    int n_lo, n_hi;
+    if (HDR)
+        {
+            n_lo = 0;
+            n_hi = max(N - 1, 0);
+        }
+    else
+        {
+            n_lo = max(c0 * TRK_CHUNK - a, 0);
+            n_hi = max(min(c1 * TRK_CHUNK - a, N) - 1, n_lo);
+        }
+    float smin = shifts[0], smax = shifts[0];
+    if (!HDR)
+        {
+#pragma unroll
+            for (int t = 1; t < NTAPS; t++)
+                {
+                    smin = fminf(smin, shifts[t]);
+                    smax = fmaxf(smax, shifts[t]);
+                }
+        }
+    int lo, hi;
+    bool monotone;
+    if (HDR)
+        {
+            lo = chip_index_hd(step, rate, (unsigned)n_lo, shifts[0], rem);
+            hi = chip_index_hd(step, rate, (unsigned)n_hi, shifts[0], rem);
+            // float ops are monotone, so the index is monotone in n when both terms are
+            monotone = (step > 0.0f) && (rate >= 0.0f) && ((unsigned long long)n_hi * n_hi < 0xffffffffull);
+        }
+    else
+        {
+            lo = chip_index(step, (float)n_lo, smin, rem);
+            hi = chip_index(step, (float)n_hi, smax, rem);
+            monotone = (step >= 0.0f);
+        }
+    const long long span_ll = (long long)hi - (long long)lo + 1;
+    const bool windowed = monotone && span_ll > 0 && span_ll <= (long long)lds_table_floats;
+    const GC_GLOBAL float* code = (const GC_GLOBAL float*)cd.code;
+    if (windowed)
+        {
+            const int span = (int)span_ll;
+            const int cbase = posmod(lo, L);
+            if (cbase + span <= 3 * L)
+                {
+                    for (int k = tid; k < span; k += TRK_THREADS)
+                        {
+                            int i = cbase + k;  // < 3L: two conditional subtractions instead of a division
+                            i = (i >= L) ? i - L : i;
+                            i = (i >= L) ? i - L : i;
+                            table[k] = code[i];
+                        }
+                }
+            else
+                {
+                    for (int k = tid; k < span; k += TRK_THREADS) table[k] = code[(cbase + k) % L];
+                }
+        }
+    else
+        {
+            for (int k = tid; k < L; k += TRK_THREADS) table[k] = code[k];
+        }
+    __syncthreads();
+
+    float accr[NTAPS], acci[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; t++) accr[t] = acci[t] = 0.0f;
+
+    if (windowed)
+        trk_loop<NTAPS, HDR, HDC, true, FMT>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+    else
+        trk_loop<NTAPS, HDR, HDC, false, FMT>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+
+    // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
+    __syncthreads();  // the code window has been consumed by every thread
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < NTAPS; t++)
+        {
+            float sr = wave_sum(accr[t]);
+            float si = wave_sum(acci[t]);
+            if (lane == 63)
+                {
+                    lds[(wave * NTAPS + t) * 2 + 0] = sr;
+                    lds[(wave * NTAPS + t) * 2 + 1] = si;
+                }
+        }
+    __syncthreads();
+    float2 r = make_float2(0.f, 0.f);
+    if (tid < NTAPS)
+        {
+            float sr = 0.f, si = 0.f;
+#pragma unroll
+            for (int w = 0; w < TRK_THREADS / 64; w++)
+                {
+                    sr += lds[(w * NTAPS + tid) * 2 + 0];
+                    si += lds[(w * NTAPS + tid) * 2 + 1];
+                }
+            r = make_float2(sr, si);
+        }
+    return r;
+}
+
+#endif  // TRK_DEVICE_HPP

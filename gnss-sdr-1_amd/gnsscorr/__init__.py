@@ -92,6 +92,31 @@ class AcqResult(C.Structure):
     ]
 
 
+class LoopConf(C.Structure):
+    """gc_loop_conf."""
+    _fields_ = [
+        ("fs_in", C.c_double), ("signal_carrier_freq_hz", C.c_double), ("code_chip_rate_hz", C.c_double),
+        ("code_period_s", C.c_double), ("carrier_lock_th", C.c_double), ("acq_delay_samples", C.c_double),
+        ("acq_doppler_hz", C.c_double), ("acq_samplestamp_samples", C.c_uint64), ("sample_counter", C.c_uint64),
+        ("code_length_chips", C.c_uint32), ("code_samples_per_chip", C.c_uint32), ("vector_length", C.c_uint32),
+        ("pull_in_time_s", C.c_uint32), ("veml", C.c_int32), ("pll_filter_order", C.c_int32), ("dll_filter_order", C.c_int32),
+        ("enable_fll_pull_in", C.c_int32), ("enable_fll_steady_state", C.c_int32), ("cn0_samples", C.c_int32),
+        ("cn0_min", C.c_int32), ("max_lock_fail", C.c_int32), ("pll_bw_hz", C.c_float), ("dll_bw_hz", C.c_float),
+        ("fll_bw_hz", C.c_float), ("early_late_space_chips", C.c_float), ("very_early_late_space_chips", C.c_float),
+        ("reserved", C.c_uint32),
+    ]
+
+
+LOOP_RECORD_DTYPE = np.dtype([
+    ("corr", np.float32, (10,)), ("carrier_doppler_hz", np.float32), ("code_freq_chips", np.float32),
+    ("carr_phase_error_hz", np.float32), ("carr_error_filt_hz", np.float32), ("code_error_chips", np.float32),
+    ("code_error_filt_chips", np.float32), ("cn0_db_hz", np.float32), ("carrier_lock_test", np.float32),
+    ("sample_counter", np.uint64), ("acc_carrier_phase_rad", np.float64), ("rem_code_phase_samples", np.float64),
+    ("state", np.int32), ("valid", np.int32), ("current_prn_length_samples", np.int32), ("reserved", np.int32),
+], align=True)
+assert LOOP_RECORD_DTYPE.itemsize == 112 and C.sizeof(LoopConf) == 144
+
+
 # every symbol include/gnsscorr.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 _fp = C.POINTER(C.c_float)
@@ -122,6 +147,12 @@ API = {
     "gc_trk_batch_run": (C.c_int, [_vp, C.c_int, _vp, _fp]),
     "gc_trk_batch_set_nominal_length": (C.c_int, [_vp, C.c_int]),
     "gc_trk_batch_set_slices": (C.c_int, [_vp, C.c_int]),
+    "gc_trk_loop_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "gc_trk_loop_destroy": (C.c_int, [_vp]),
+    "gc_trk_loop_set_input_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
+    "gc_trk_loop_start": (C.c_int, [_vp, C.c_int, C.POINTER(LoopConf), _fp, C.c_int]),
+    "gc_trk_loop_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "gc_trk_loop_run": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_gps_l1_ca_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
     "gc_gps_l1_ca_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
     "gc_beidou_b1i_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
@@ -385,6 +416,43 @@ class TrackingBatch:
     def close(self):
         if self._h:
             load_library().gc_trk_batch_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TrackingLoop:
+    """gc_trk_loop: closed-loop DLL/PLL tracking on the device (correlations + loop maths per epoch in one launch)."""
+
+    def __init__(self, ctx, n_channels, max_code_length):
+        self._ctx = ctx
+        self.n_channels = n_channels
+        self._h = _vp()
+        _check(load_library().gc_trk_loop_create(ctx._h, n_channels, max_code_length, C.byref(self._h)))
+
+    def set_input_dev(self, ch, dev_ptr, n_samples):
+        _check(load_library().gc_trk_loop_set_input_dev(self._h, ch, _vp(dev_ptr), int(n_samples)))
+
+    def start(self, ch, conf, code):
+        code = np.ascontiguousarray(code, np.float32)
+        _check(load_library().gc_trk_loop_start(self._h, ch, C.byref(conf), _f32p(code), code.size))
+
+    def run(self, n_epochs):
+        """Returns a structured array [n_channels, n_epochs] of LOOP_RECORD_DTYPE."""
+        out = np.zeros((self.n_channels, n_epochs), LOOP_RECORD_DTYPE)
+        _check(load_library().gc_trk_loop_run(self._h, n_epochs, out.ctypes.data_as(_vp)))
+        return out
+
+    def run_dev(self, n_epochs, dev_records_ptr, stream=None):
+        _check(load_library().gc_trk_loop_run_dev(self._h, n_epochs, _vp(dev_records_ptr), _vp(stream or 0)))
+
+    def close(self):
+        if self._h:
+            load_library().gc_trk_loop_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):

@@ -167,6 +167,69 @@ gc_status gc_trk_batch_set_nominal_length(gc_trk_batch* b, int n_samples);
 gc_status gc_trk_batch_set_slices(gc_trk_batch* b, int n_slices);
 
 /* ------------------------------------------------------------------------ */
+/* Level 3 -- closed-loop tracking on the device: the correlations AND the      */
+/* per-epoch DLL/PLL maths of dll_pll_veml_tracking run inside one launch for    */
+/* n_epochs code periods per channel (no host round trip per millisecond).       */
+/* ------------------------------------------------------------------------ */
+
+/* What the tracking block knows when start_tracking() is called: the Dll_Pll_Conf fields it reads
+ * (src/algorithms/tracking/libs/dll_pll_conf.h:39-80), the per-signal constants of its constructor
+ * (dll_pll_veml_tracking.cc:113-330) and the acquisition hand-over from Gnss_Synchro (:555-557). */
+typedef struct
+{
+    double fs_in;
+    double signal_carrier_freq_hz;
+    double code_chip_rate_hz;
+    double code_period_s;
+    double carrier_lock_th;
+    double acq_delay_samples;          /* Gnss_Synchro::Acq_delay_samples */
+    double acq_doppler_hz;             /* Gnss_Synchro::Acq_doppler_hz */
+    uint64_t acq_samplestamp_samples;  /* Gnss_Synchro::Acq_samplestamp_samples */
+    uint64_t sample_counter;           /* stream sample count at the first sample of the channel's IQ buffer */
+    uint32_t code_length_chips;
+    uint32_t code_samples_per_chip;
+    uint32_t vector_length;
+    uint32_t pull_in_time_s;
+    int32_t veml;                      /* != 0: 5 taps VE/E/P/L/VL (Galileo E1), else 3 taps E/P/L */
+    int32_t pll_filter_order, dll_filter_order;
+    int32_t enable_fll_pull_in, enable_fll_steady_state;
+    int32_t cn0_samples, cn0_min, max_lock_fail;
+    float pll_bw_hz, dll_bw_hz, fll_bw_hz;
+    float early_late_space_chips, very_early_late_space_chips;
+    uint32_t reserved;
+} gc_loop_conf;
+
+/* One code period of one channel: the correlator outputs plus what the block writes to Gnss_Synchro
+ * (dll_pll_veml_tracking.cc:1730-1770, 1898-1906) and to its binary dump (:1196-1243). */
+typedef struct
+{
+    float corr[10];              /* n_taps complex correlator outputs (re, im) */
+    float carrier_doppler_hz, code_freq_chips;
+    float carr_phase_error_hz, carr_error_filt_hz, code_error_chips, code_error_filt_chips;
+    float cn0_db_hz, carrier_lock_test;
+    uint64_t sample_counter;     /* Tracking_sample_counter after this epoch */
+    double acc_carrier_phase_rad;
+    double rem_code_phase_samples;
+    int32_t state;               /* 2 = tracking, 0 = standby (after loss of lock), 1 = pull-in pending */
+    int32_t valid;               /* Flag_valid_symbol_output */
+    int32_t current_prn_length_samples;
+    int32_t reserved;
+} gc_loop_record;
+
+typedef struct gc_trk_loop gc_trk_loop;
+gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, gc_trk_loop** out);
+gc_status gc_trk_loop_destroy(gc_trk_loop* l);
+/* IQ block of channel `ch` in HBM (gr_complex); epochs are correlated until it is exhausted. */
+gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, uint64_t n_samples);
+/* dll_pll_veml_tracking::start_tracking (:549-747): uploads the replica (code_length_chips *
+ * code_samples_per_chip floats), sets the taps from the spacings and initialises the loop. */
+gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, const float* code, int code_length);
+/* n_epochs code periods of every channel in ONE launch.  dev_records: n_channels*n_epochs records,
+ * channel-major.  The loop state persists on the device between calls. */
+gc_status gc_trk_loop_run_dev(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, void* stream);
+gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_records);
+
+/* ------------------------------------------------------------------------ */
 /* PRN replica generators (host side, set-up path).  Same outputs as the      */
 /* reference's generators; dest buffers are caller-owned host memory.         */
 /* ------------------------------------------------------------------------ */

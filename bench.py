@@ -270,6 +270,39 @@ def main():
             b16.close()
             del q_streams
 
+        # ---- closed loop on the device: 256 channels x 25 Msps, DLL/PLL maths in the kernel, no host round trip ----
+        if not args.no_shared:
+            n_cl, e_cl = 256, min(E, 64)
+            loop = gnsscorr.TrackingLoop(ctx, n_cl, CODE_LEN)
+            t0_ = truths[0]
+            delay = ((CODE_LEN - t0_["tau0"]) % CODE_LEN) * FS / 1.023e6
+            lc = gnsscorr.LoopConf()
+            for k_, v_ in dict(fs_in=float(FS), signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=1.023e6, code_period_s=0.001, carrier_lock_th=0.85,
+                    code_length_chips=CODE_LEN, code_samples_per_chip=1, vector_length=N_EPOCH, pull_in_time_s=2, veml=0, pll_filter_order=3,
+                    dll_filter_order=2, cn0_samples=20, cn0_min=25, max_lock_fail=50, pll_bw_hz=40.0, dll_bw_hz=2.0, fll_bw_hz=35.0,
+                    early_late_space_chips=0.5, acq_delay_samples=float(np.round(delay)), acq_doppler_hz=float(np.round(t0_["doppler"] / 10) * 10)).items():
+                setattr(lc, k_, v_)
+            d_recs = torch.zeros(n_cl * e_cl * gnsscorr.LOOP_RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            def cl_run():
+                for ch in range(n_cl):
+                    loop.set_input_dev(ch, streams[0].data_ptr(), n_stream)
+                    loop.start(ch, lc, codes[0])
+                torch.cuda.synchronize()
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                loop.run_dev(e_cl, d_recs.data_ptr(), stream)
+                c1.record()
+                torch.cuda.synchronize()
+                return c0.elapsed_time(c1)
+            cl_run()
+            cl_ms = min(cl_run() for _ in range(3))
+            recs = np.frombuffer(d_recs.cpu().numpy().tobytes(), gnsscorr.LOOP_RECORD_DTYPE).reshape(n_cl, e_cl)
+            assert np.all(recs["valid"][:, :e_cl - 2] == 1)
+            extra["closed_loop"] = {"channels": n_cl, "epochs": e_cl, "ms": cl_ms, "realtime_factor": e_cl * 1.0 / cl_ms,
+                "value": n_cl * e_cl * N_EPOCH / (cl_ms * 1e-3) / 1e6, "unit": "Msamples/s",
+                "note": "256 channels tracked in closed loop (DLL/PLL maths on the device), one workgroup per channel, shared RF stream"}
+            loop.close()
+
         # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----
         if not args.no_acq:
             acq = gnsscorr.PcpsAcquisition(ctx, 32, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,

@@ -270,6 +270,39 @@ def main():
             b16.close()
             del q_streams
 
+        # ---- BASELINE configs[2] shape: Galileo E1, 5 taps (VE/E/P/L/VL), L = 8184 (2 samples/chip), 4 ms epochs ----
+        if not args.no_shared:
+            n_gal, e_gal = 100000, max(1, E // 4)
+            bg = gnsscorr.TrackingBatch(ctx, N_CHANNELS, 5, 8184)
+            rng_g = np.random.Generator(np.random.PCG64(1003))
+            gshifts = np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32)
+            grecs = []
+            for ch in range(N_CHANNELS):
+                prim = np.sign(rng_g.standard_normal(4092)).astype(np.float32)  # memory-code stand-in: timing does not depend on the chips
+                boc = np.empty(8184, np.float32)
+                boc[0::2], boc[1::2] = prim, -prim
+                bg.set_code(ch, boc, gshifts)
+                bg.set_input_dev(ch, streams[ch].data_ptr(), n_stream)
+                grecs.append([gnsscorr.epoch_params(k * n_gal, 0.1, float(np.float32(2 * np.pi * 1000.0 / FS)), 0.3, float(np.float32(2.046e6 / FS)), n_gal)
+                    for k in range(e_gal)])
+            d_gp = torch.from_numpy(gnsscorr.epoch_params_array(grecs).view(np.uint8)).to(dev)
+            d_go = torch.zeros(N_CHANNELS * e_gal * 5, 2, device=dev, dtype=torch.float32)
+            for _ in range(2):
+                bg.run_dev(e_gal, d_gp.data_ptr(), d_go.data_ptr(), stream)
+            torch.cuda.synchronize()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(args.steps):
+                bg.run_dev(e_gal, d_gp.data_ptr(), d_go.data_ptr(), stream)
+            g1.record()
+            torch.cuda.synchronize()
+            gal_ms = g0.elapsed_time(g1) / args.steps
+            gal_samples = N_CHANNELS * e_gal * n_gal
+            extra["galileo_e1_5tap"] = {"value": gal_samples / (gal_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": gal_ms,
+                "hbm_gbps": 8.0 * gal_samples / (gal_ms * 1e-3) / 1e9,
+                "note": "32 channels, 25 Msps, 5 taps, L = 8184, N = 100000 (4 ms), distinct IQ buffer per channel"}
+            bg.close()
+
         # ---- closed loop on the device: 256 channels x 25 Msps, DLL/PLL maths in the kernel, no host round trip ----
         if not args.no_shared:
             n_cl, e_cl = 256, min(E, 64)

@@ -5,10 +5,15 @@
 //     (src/tests/unit-tests/signal-processing-blocks/acquisition/gps_l1_ca_pcps_acquisition_test.cc:276-362)
 //   GalileoE1PcpsAmbiguousAcquisitionTest.ValidationOfResults (…/galileo_e1_pcps_ambiguous_acquisition_test.cc:283-360)
 //   CPU_multicorrelator_real_codes_test (…/tracking/cpu_multicorrelator_real_codes_test.cc:68-171) -- with values asserted.
+//   CpuMulticorrelatorTest.MeasureExecutionTime (…/tracking/cpu_multicorrelator_test.cc:66-170) -- same set-up
+//     (complex C/A replica, sizes 2048/4096/8192, step 0.3, rem 0.4, carrier step 0.1, concurrent objects), values asserted.
 // Usage: adapter_selftest <tests/golden directory>.  Needs a GPU (run by pytest -m gpu).
+#include "hip_multicorrelator.h"
 #include "hip_multicorrelator_real_codes.h"
 #include "pcps_acquisition_adapters.h"
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 #include <cstdio>
 #include <fstream>
 #include <string>
@@ -93,6 +98,71 @@ static void test_multicorrelator()
     std::printf("multicorrelator: noiseless E/P/L = 2004/4000/1992 reproduced; narrow spacing E=(%g,%g) P=(%g,%g) L=(%g,%g)\n", out[0].real(), out[0].imag(), out[1].real(), out[1].imag(), out[2].real(), out[2].imag());
 }
 
+static void test_multicorrelator_complex()
+{
+    const int sizes[3] = {2048, 4096, 8192};
+    const int n_threads = 4;
+    float chips[1023];
+    gc_gps_l1_ca_code_gen_float(chips, 1, 0);
+    std::vector<std::complex<float>> code(1023);
+    for (int i = 0; i < 1023; i++) code[i] = std::complex<float>(chips[i], 0.0f);  // gps_l1_ca_code_gen_complex
+    std::vector<std::complex<float>> in(2 * sizes[2]);
+    unsigned lcg = 12345u;
+    for (auto& v : in)
+        {
+            lcg = lcg * 1664525u + 1013904223u;
+            const float a = (lcg >> 8) * (1.0f / 16777216.0f);
+            lcg = lcg * 1664525u + 1013904223u;
+            v = std::complex<float>(a, (lcg >> 8) * (1.0f / 16777216.0f));  // uniform [0,1) like the reference test
+        }
+    float shifts[3] = {-0.5f, 0.0f, 0.5f};
+    const float rem_carr = 0.0f, carr_step = 0.1f, code_step = 0.3f, rem_code = 0.4f;
+    std::vector<std::complex<float>> outs(3 * n_threads);
+    std::vector<Hip_Multicorrelator> pool(n_threads);
+    for (int t = 0; t < n_threads; t++)
+        {
+            EXPECT(pool[t].init(sizes[2], 3), "init");
+            EXPECT(pool[t].set_input_output_vectors(&outs[3 * t], in.data()), "set_input_output_vectors");
+            EXPECT(pool[t].set_local_code_and_taps(1023, code.data(), shifts), "set_local_code_and_taps");
+        }
+    for (int si = 0; si < 3; si++)
+        {
+            const int N = sizes[si];
+            std::vector<std::thread> threads;
+            for (int t = 0; t < n_threads; t++)
+                threads.emplace_back([&, t]() {
+                    for (int k = 0; k < 20; k++) pool[t].Carrier_wipeoff_multicorrelator_resampler(rem_carr, carr_step, rem_code, code_step, N);
+                });
+            for (auto& th : threads) th.join();
+            // float64 evaluation of the same sums
+            std::complex<double> want[3];
+            for (int n = 0; n < N; n++)
+                {
+                    const std::complex<double> y = std::complex<double>(in[n]) * std::exp(std::complex<double>(0.0, -static_cast<double>(carr_step) * n));
+                    for (int t = 0; t < 3; t++)
+                        {
+                            int i = static_cast<int>(std::floor(code_step * static_cast<float>(n) + shifts[t] - rem_code));
+                            i = ((i % 1023) + 1023) % 1023;
+                            want[t] += y * static_cast<double>(chips[i]);
+                        }
+                }
+            double scale = 0.0;
+            for (int t = 0; t < 3; t++) scale = std::max(scale, std::abs(want[t]));
+            for (int th = 0; th < n_threads; th++)
+                {
+                    EXPECT(pool[th].last_status() == GC_OK, "status %d: %s", pool[th].last_status(), gc_last_error());
+                    for (int t = 0; t < 3; t++)
+                        {
+                            const double err = std::abs(std::complex<double>(outs[3 * th + t]) - want[t]);
+                            // the input has a DC offset (uniform [0,1)): the sums are small residues of N terms of order 1, so gate on N
+                            EXPECT(err <= 2e-5 * N, "complex correlator N=%d thread %d tap %d: err %g (|sum| %g)", N, th, t, err, scale);
+                        }
+                }
+        }
+    for (auto& c : pool) EXPECT(c.free(), "free");
+    std::printf("complex-chip multicorrelator: 4 concurrent objects x sizes 2048/4096/8192 agree with the float64 sums\n");
+}
+
 struct CountingFsm : public ChannelFsm
 {
     int valid = 0;
@@ -125,6 +195,13 @@ static void test_gps_acquisition(const std::string& dir, bool two_steps)
     config.set_property("Acquisition_1C.doppler_max", "5000");
     config.set_property("Acquisition_1C.doppler_step", "100");
     if (two_steps) config.set_property("Acquisition_1C.make_two_steps", "true");
+    if (const char* dump_dir = std::getenv("GNSSCORR_SELFTEST_DUMP_DIR"))
+        {
+            // acquisition dump as in the reference (`dump`, `dump_filename`, `dump_channel`; pcps_acquisition.cc:462-562)
+            config.set_property("Acquisition_1C.dump", "true");
+            config.set_property("Acquisition_1C.dump_channel", "1");
+            config.set_property("Acquisition_1C.dump_filename", std::string(dump_dir) + (two_steps ? "/sub/acq_two_steps.mat" : "/acq_dump.mat"));
+        }
     Gnss_Synchro gnss_synchro;
     gnss_synchro.Channel_ID = 0;
     gnss_synchro.System = 'G';
@@ -153,6 +230,7 @@ static void test_gps_acquisition(const std::string& dir, bool two_steps)
     EXPECT(doppler_error_hz <= (two_steps ? 125.0 : 666.0), "Doppler %g Hz", gnss_synchro.Acq_doppler_hz);
     EXPECT(delay_error_chips < 0.5, "delay %g samples", gnss_synchro.Acq_delay_samples);
     if (two_steps) EXPECT(gnss_synchro.Acq_doppler_step == 125, "Acq_doppler_step %u", gnss_synchro.Acq_doppler_step);
+    if (std::getenv("GNSSCORR_SELFTEST_DUMP_DIR")) EXPECT(!blk->last_dump_file().empty(), "no acquisition dump written");
     std::printf("GPS L1 C/A acquisition%s: delay %g samples, Doppler %g Hz, statistic %g, stamp %llu\n", two_steps ? " (two steps)" : "",
         gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz, blk->test_statistics(), (unsigned long long)gnss_synchro.Acq_samplestamp_samples);
 
@@ -255,6 +333,7 @@ int main(int argc, char** argv)
             return 3;
         }
     test_multicorrelator();
+    test_multicorrelator_complex();
     test_gps_acquisition(argv[1], false);
     test_gps_acquisition(argv[1], true);
     test_galileo_acquisition(argv[1]);

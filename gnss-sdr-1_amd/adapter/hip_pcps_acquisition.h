@@ -20,9 +20,13 @@
 #include "gnss_sdr_types.h"
 #include "gnsscorr.h"
 #include "hip_multicorrelator_real_codes.h"  // gnsscorr::shared_context()
+#include "mat5_writer.h"
 #include <cmath>
 #include <cstring>
+#include <iostream>
 #include <mutex>
+#include <string>
+#include <sys/stat.h>
 #include <vector>
 
 class hip_pcps_acquisition
@@ -41,6 +45,33 @@ public:
         d_use_CFAR_algorithm_flag = (acq_parameters.max_dwells == 1) ? acq_parameters.use_CFAR_algorithm_flag : false;
         d_num_doppler_bins_step2 = acq_parameters.num_doppler_bins_step2;
         d_data_buffer.resize(d_consumed_samples);
+        // dump file name handling of the reference constructor (:160-193)
+        d_dump_channel = acq_parameters.dump_channel;
+        d_dump = acq_parameters.dump;
+        d_dump_filename = acq_parameters.dump_filename;
+        if (d_dump)
+            {
+                std::string dump_path;
+                if (d_dump_filename.find_last_of('/') != std::string::npos)
+                    {
+                        const std::string dump_filename_ = d_dump_filename.substr(d_dump_filename.find_last_of('/') + 1);
+                        dump_path = d_dump_filename.substr(0, d_dump_filename.find_last_of('/'));
+                        d_dump_filename = dump_filename_;
+                    }
+                else
+                    {
+                        dump_path = std::string(".");
+                    }
+                if (d_dump_filename.empty()) d_dump_filename = "acquisition";
+                // remove extension if any
+                if (d_dump_filename.substr(1).find_last_of('.') != std::string::npos) d_dump_filename = d_dump_filename.substr(0, d_dump_filename.find_last_of('.'));
+                d_dump_filename = dump_path + '/' + d_dump_filename;
+                if (!create_directory(dump_path))
+                    {
+                        std::cerr << "GNSS-SDR cannot create dump file for the Acquisition block. Wrong permissions?" << std::endl;
+                        d_dump = false;
+                    }
+            }
     }
 
     ~hip_pcps_acquisition()
@@ -99,6 +130,13 @@ public:
         d_status = ctx ? gc_acq_create(ctx, &c, 1, &d_acq) : GC_ERR_NO_DEVICE;
         if (d_status == GC_OK && !d_code.empty()) d_status = gc_acq_set_local_code(d_acq, 0, reinterpret_cast<const float*>(d_code.data()));
         d_worker_active = false;
+        if (d_dump)
+            {
+                // (:364-369)
+                const uint32_t effective_fft_size = (acq_parameters.bit_transition_flag ? (d_fft_size / 2) : d_fft_size);
+                grid_.assign(static_cast<size_t>(effective_fft_size) * d_num_doppler_bins, 0.0f);
+                narrow_grid_.assign(static_cast<size_t>(effective_fft_size) * d_num_doppler_bins_step2, 0.0f);
+            }
     }
 
     /*! pcps_acquisition::set_local_code (:239-274): code = d_consumed_samples complex (fft_size/2 with bit transition) */
@@ -238,6 +276,20 @@ public:
         d_test_statistics = r.test_statistics;
         d_input_power = r.input_power;
         d_last = r;
+        const uint32_t effective_fft_size = (acq_parameters.bit_transition_flag ? (d_fft_size / 2) : d_fft_size);
+        if (d_dump and d_channel == d_dump_channel and d_status == GC_OK)
+            {
+                // "Record results to file if required" (:741-744, :799-802): the reference copies each
+                // accumulated grid row after it is updated; here the rows come back from HBM in one piece
+                const uint32_t bins = d_step_two ? d_num_doppler_bins_step2 : d_num_doppler_bins;
+                std::vector<float>& dst = d_step_two ? narrow_grid_ : grid_;
+                d_grid_tmp.resize(static_cast<size_t>(bins) * d_fft_size);
+                if (gc_acq_get_grid(d_acq, 0, d_grid_tmp.data()) == GC_OK)
+                    {
+                        for (uint32_t b = 0; b < bins; b++)
+                            std::memcpy(&dst[static_cast<size_t>(b) * effective_fft_size], &d_grid_tmp[static_cast<size_t>(b) * d_fft_size], sizeof(float) * effective_fft_size);
+                    }
+            }
         if (acq_parameters.use_automatic_resampler)
             {
                 d_gnss_synchro->Acq_delay_samples = r.acq_delay_samples * acq_parameters.resampler_ratio;
@@ -331,6 +383,8 @@ public:
         d_worker_active = false;
         if ((d_num_noncoherent_integrations_counter == acq_parameters.max_dwells) or (d_positive_acq == 1))
             {
+                // Record results to file if required (:913-918)
+                if (d_dump and d_channel == d_dump_channel) dump_results(effective_fft_size);
                 d_num_noncoherent_integrations_counter = 0U;
                 d_positive_acq = 0;
                 if (d_acq != nullptr)
@@ -355,7 +409,69 @@ public:
     uint64_t sample_counter() const { return d_sample_counter; }
     gc_status last_status() const { return d_status; }
 
+    //! name of the last file dump_results() wrote ("" if none)
+    const std::string& last_dump_file() const { return d_last_dump_file; }
+
 private:
+    static bool create_directory(const std::string& path)
+    {
+        // gnss_sdr_create_directory (src/algorithms/libs/gnss_sdr_create_directory.cc): mkdir -p
+        if (path.empty() || path == "." || path == "/") return true;
+        struct stat st;
+        if (::stat(path.c_str(), &st) == 0) return S_ISDIR(st.st_mode);
+        const size_t slash = path.find_last_of('/');
+        if (slash != std::string::npos && slash > 0 && !create_directory(path.substr(0, slash))) return false;
+        return ::mkdir(path.c_str(), 0775) == 0 || (::stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode));
+    }
+
+    /*! pcps_acquisition::dump_results (:462-562): same file name, variable names, classes and
+     *  dimensions; Level-5 container instead of matio's v7.3 (see mat5_writer.h). */
+    void dump_results(int32_t effective_fft_size)
+    {
+        d_dump_number++;
+        std::string filename = d_dump_filename;
+        filename.append("_");
+        filename.append(1, d_gnss_synchro->System);
+        filename.append("_");
+        filename.append(1, d_gnss_synchro->Signal[0]);
+        filename.append(1, d_gnss_synchro->Signal[1]);
+        filename.append("_ch_");
+        filename.append(std::to_string(d_channel));
+        filename.append("_");
+        filename.append(std::to_string(d_dump_number));
+        filename.append("_sat_");
+        filename.append(std::to_string(d_gnss_synchro->PRN));
+        filename.append(".mat");
+
+        gnsscorr::Mat5Writer mat;
+        if (!mat.open(filename))
+            {
+                std::cout << "Unable to create or open Acquisition dump file" << std::endl;
+                return;
+            }
+        bool ok = mat.write_single_matrix("acq_grid", static_cast<size_t>(effective_fft_size), d_num_doppler_bins, grid_.data());
+        ok = ok && mat.write_scalar("doppler_max", static_cast<uint32_t>(acq_parameters.doppler_max));
+        ok = ok && mat.write_scalar("doppler_step", static_cast<uint32_t>(d_doppler_step));
+        ok = ok && mat.write_scalar("d_positive_acq", static_cast<int32_t>(d_positive_acq));
+        ok = ok && mat.write_scalar("acq_doppler_hz", static_cast<float>(d_gnss_synchro->Acq_doppler_hz));
+        ok = ok && mat.write_scalar("acq_delay_samples", static_cast<float>(d_gnss_synchro->Acq_delay_samples));
+        ok = ok && mat.write_scalar("test_statistic", d_test_statistics);
+        ok = ok && mat.write_scalar("threshold", d_threshold);
+        ok = ok && mat.write_scalar("input_power", d_input_power);
+        ok = ok && mat.write_scalar("sample_counter", static_cast<uint64_t>(d_sample_counter));
+        ok = ok && mat.write_scalar("PRN", static_cast<uint32_t>(d_gnss_synchro->PRN));
+        ok = ok && mat.write_scalar("num_dwells", static_cast<uint32_t>(d_num_noncoherent_integrations_counter));
+        if (acq_parameters.make_2_steps)
+            {
+                ok = ok && mat.write_single_matrix("acq_grid_narrow", static_cast<size_t>(effective_fft_size), d_num_doppler_bins_step2, narrow_grid_.data());
+                ok = ok && mat.write_scalar("doppler_step_narrow", static_cast<float>(acq_parameters.doppler_step2));
+                const float aux = d_doppler_center_step_two - static_cast<float>(std::floor(d_num_doppler_bins_step2 / 2.0)) * acq_parameters.doppler_step2;
+                ok = ok && mat.write_scalar("doppler_grid_narrow_min", aux);
+            }
+        mat.close();
+        if (ok) d_last_dump_file = filename;
+    }
+
     void send_positive_acquisition()
     {
         d_positive_acq = 1;
@@ -372,6 +488,12 @@ private:
     }
 
     Acq_Conf acq_parameters;
+    bool d_dump = false;
+    uint32_t d_dump_channel = 0U;
+    int64_t d_dump_number = 0LL;
+    std::string d_dump_filename;
+    std::string d_last_dump_file;
+    std::vector<float> grid_, narrow_grid_, d_grid_tmp;
     gc_acq* d_acq = nullptr;
     gc_status d_status = GC_OK;
     gc_acq_result d_last{};

@@ -6,7 +6,8 @@
  *   GpsL1CaPcpsAcquisition           src/algorithms/acquisition/adapters/gps_l1_ca_pcps_acquisition.cc:46-358
  *   GalileoE1PcpsAmbiguousAcquisition src/algorithms/acquisition/adapters/galileo_e1_pcps_ambiguous_acquisition.cc:46-330
  *   BeidouB1iPcpsAcquisition          src/algorithms/acquisition/adapters/beidou_b1i_pcps_acquisition.cc:45-330
- * (item_type gr_complex only; the acquisition resampler, dump files and the GNU Radio
+ * (item_type gr_complex only; `dump` / `dump_filename` / `dump_channel` write the reference's .mat
+ * variables, see hip_pcps_acquisition::dump_results; the acquisition resampler and the GNU Radio
  * connect()/get_left_block() plumbing are outside this path).  Registration in a GNSS-SDR tree is one
  * more `else if (implementation == "GPS_L1_CA_PCPS_Acquisition_HIP")` in
  * GNSSBlockFactory::GetAcqBlock (src/core/receiver/gnss_block_factory.cc:1946), see INTEGRATION.md.
@@ -78,6 +79,10 @@ public:
         acq_parameters_.num_doppler_bins_step2 = configuration_->property(role + ".second_nbins", 4);
         acq_parameters_.doppler_step2 = configuration_->property(role + ".second_doppler_step", 125.0f);
         acq_parameters_.make_2_steps = configuration_->property(role + ".make_two_steps", false);
+        // gps_l1_ca_pcps_acquisition.cc:56,64-66,84-85
+        acq_parameters_.dump = configuration_->property(role + ".dump", false);
+        acq_parameters_.dump_channel = configuration_->property(role + ".dump_channel", 0);
+        acq_parameters_.dump_filename = configuration_->property(role + ".dump_filename", std::string("./acquisition.mat"));
         acq_parameters_.it_size = sizeof(gr_complex);
         if (SIG == AcqSignal::GPS_L1_CA)
             {

@@ -3,6 +3,8 @@
 //   * gc_correlator_*  : one object per channel with the method set of the
 //                        reference's Cpu_Multicorrelator_Real_Codes
 //                        (src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.h:45-69)
+//                        and, with complex chips, of Cpu_Multicorrelator
+//                        (src/algorithms/tracking/libs/cpu_multicorrelator.h:46-64)
 #include "gc_internal.h"
 #include "trk_kernels.h"
 #include <cmath>
@@ -46,6 +48,7 @@ struct gc_trk_batch
     int nominal_len = 0;
     int iq_format = GC_IQ_F32;
     int forced_slices = 0;
+    bool complex_codes = false;
     std::vector<TrkChan> h_chans;
     bool chans_dirty = true;
     TrkChan* d_chans = nullptr;
@@ -154,8 +157,53 @@ gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int 
     GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_code: channel %d out of range", ch);
     GC_REQUIRE(code_length > 0 && code_length <= b->max_code_len, "gc_trk_batch_set_code: code_length %d not in 1..%d",
         code_length, b->max_code_len);
+    if (b->complex_codes) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code: the batch holds complex codes (gc_trk_batch_set_code_complex)");
     gc_device_guard g(b->ctx->device);
     GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * b->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
+    b->h_chans[ch].code_len = code_length;
+    return gc_trk_batch_set_shifts(b, ch, shifts_chips);
+}
+
+gc_status gc_trk_batch_set_complex_codes(gc_trk_batch* b, int on)
+{
+    GC_REQUIRE(b, "gc_trk_batch_set_complex_codes: NULL argument");
+    const bool want = on != 0;
+    if (want == b->complex_codes) return GC_OK;
+    if (want && b->mode != TRK_MODE_PLAIN)
+        return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_complex_codes: the complex-code correlator has no high-dynamics variant");
+    const int per_chip = want ? 2 : 1;
+    GC_REQUIRE(per_chip * (b->max_code_len + 64) <= kMaxLdsTableFloats,
+        "gc_trk_batch_set_complex_codes: max_code_length %d too long for complex chips (max %d)", b->max_code_len, kMaxLdsTableFloats / 2 - 64);
+    gc_device_guard g(b->ctx->device);
+    std::lock_guard<std::mutex> lk(b->ctx->mtx);
+    GC_HIP(hipStreamSynchronize(b->ctx->stream));
+    float* d_new = nullptr;
+    const size_t stride = (size_t)per_chip * b->max_code_len;
+    GC_HIP(hipMalloc(&d_new, sizeof(float) * (size_t)b->n_channels * stride));
+    (void)hipMemset(d_new, 0, sizeof(float) * (size_t)b->n_channels * stride);
+    (void)hipFree(b->d_codes);
+    b->d_codes = d_new;
+    for (int i = 0; i < b->n_channels; i++)
+        {
+            b->h_chans[i].code = b->d_codes + (size_t)i * stride;
+            b->h_chans[i].code_len = 0;  // every channel needs its code again
+        }
+    b->complex_codes = want;
+    b->mode = want ? TRK_MODE_COMPLEX_CODE : TRK_MODE_PLAIN;
+    b->lds_table_floats = per_chip * (b->max_code_len + 64);
+    b->chans_dirty = true;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_code_complex(gc_trk_batch* b, int ch, const float* code_iq, int code_length, const float* shifts_chips)
+{
+    GC_REQUIRE(b && code_iq && shifts_chips, "gc_trk_batch_set_code_complex: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_code_complex: channel %d out of range", ch);
+    GC_REQUIRE(code_length > 0 && code_length <= b->max_code_len, "gc_trk_batch_set_code_complex: code_length %d not in 1..%d",
+        code_length, b->max_code_len);
+    if (!b->complex_codes) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code_complex: call gc_trk_batch_set_complex_codes(batch, 1) first");
+    gc_device_guard g(b->ctx->device);
+    GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * 2 * b->max_code_len, code_iq, sizeof(float) * 2 * code_length, hipMemcpyHostToDevice));
     b->h_chans[ch].code_len = code_length;
     return gc_trk_batch_set_shifts(b, ch, shifts_chips);
 }
@@ -302,6 +350,7 @@ struct gc_correlator
     const float* local_code_in = nullptr;
     float* shifts_chips = nullptr;
     int code_length_chips = 0;
+    bool complex_code = false;  // local_code_in holds (re, im) pairs: Cpu_Multicorrelator
     float* corr_out = nullptr;
     const float* sig_in = nullptr;
     // device side
@@ -351,27 +400,33 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     if (!c->local_code_in || !c->shifts_chips) return gc_fail(GC_ERR_STATE, "correlator: set_local_code_and_taps() has not been called");
     if (!c->corr_out || !c->sig_in) return gc_fail(GC_ERR_STATE, "correlator: set_input_output_vectors() has not been called");
     GC_REQUIRE(N >= 0 && N <= c->max_len, "correlator: signal_length_samples %d exceeds init() capacity %d", N, c->max_len);
-    GC_REQUIRE(c->code_length_chips > 0 && c->code_length_chips + 64 <= kMaxLdsTableFloats,
-        "correlator: code_length_chips %d not supported (max %d)", c->code_length_chips, kMaxLdsTableFloats - 64);
+    const int per_chip = (mode == TRK_MODE_COMPLEX_CODE) ? 2 : 1;
+    if ((per_chip == 2) != c->complex_code)
+        return gc_fail(GC_ERR_STATE, "correlator: the local code is %s; use the matching Carrier_wipeoff overload", c->complex_code ? "complex" : "real");
+    GC_REQUIRE(c->code_length_chips > 0 && per_chip * (c->code_length_chips + 64) <= kMaxLdsTableFloats,
+        "correlator: code_length_chips %d not supported (max %d)", c->code_length_chips, kMaxLdsTableFloats / per_chip - 64);
     gc_device_guard g(c->ctx->device);
     std::lock_guard<std::mutex> lk(c->ctx->mtx);
     hipStream_t st = c->ctx->stream;
     const int L = c->code_length_chips;
+    const int LF = per_chip * L;  // floats in the code table
     // code table: the caller's buffer is re-read on every call like the reference
     // does; it is re-uploaded only when its contents changed
-    if (L > c->d_code_cap)
+    if (LF > c->d_code_cap)
         {
             (void)hipFree(c->d_code);
             c->d_code = nullptr;
             c->d_code_cap = 0;
-            GC_HIP(hipMalloc(&c->d_code, sizeof(float) * L));
-            c->d_code_cap = L;
+            GC_HIP(hipMalloc(&c->d_code, sizeof(float) * LF));
+            c->d_code_cap = LF;
             c->code_shadow.clear();
         }
-    if ((int)c->code_shadow.size() != L || std::memcmp(c->code_shadow.data(), c->local_code_in, sizeof(float) * L) != 0)
+    if ((int)c->code_shadow.size() != LF || std::memcmp(c->code_shadow.data(), c->local_code_in, sizeof(float) * LF) != 0)
         {
-            c->code_shadow.assign(c->local_code_in, c->local_code_in + L);
-            GC_HIP(hipMemcpyAsync(c->d_code, c->code_shadow.data(), sizeof(float) * L, hipMemcpyHostToDevice, st));
+            // the previous upload may still be in flight from the pageable shadow buffer
+            GC_HIP(hipStreamSynchronize(st));
+            c->code_shadow.assign(c->local_code_in, c->local_code_in + LF);
+            GC_HIP(hipMemcpyAsync(c->d_code, c->code_shadow.data(), sizeof(float) * LF, hipMemcpyHostToDevice, st));
         }
     if (N > 0) GC_HIP(hipMemcpyAsync(c->d_sig, c->sig_in, sizeof(float2) * (size_t)N, hipMemcpyHostToDevice, st));
     gc_correlator::Staging* s = c->h_stage;
@@ -389,7 +444,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     if (n_slices < 1) n_slices = 1;
     if (n_slices > c->partial_slices) n_slices = c->partial_slices;
     hipError_t e = trk_launch(c->n_corr, mode, GC_IQ_F32, st, &c->d_stage->chan, &c->d_stage->params, c->d_out, c->d_partial, 1, 1,
-        n_slices, L + 64);
+        n_slices, per_chip * (L + 64));
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
     GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, sizeof(float2) * c->n_corr, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
@@ -454,6 +509,18 @@ gc_status gc_correlator_set_local_code_and_taps(gc_correlator* c, int code_lengt
     c->local_code_in = local_code_in;
     c->shifts_chips = shifts_chips;
     c->code_length_chips = code_length_chips;
+    c->complex_code = false;
+    return GC_OK;
+}
+
+gc_status gc_correlator_set_local_code_and_taps_complex(gc_correlator* c, int code_length_chips, const float* local_code_in_iq,
+    float* shifts_chips)
+{
+    GC_REQUIRE(c, "gc_correlator_set_local_code_and_taps_complex: NULL handle");
+    c->local_code_in = local_code_in_iq;
+    c->shifts_chips = shifts_chips;
+    c->code_length_chips = code_length_chips;
+    c->complex_code = true;
     return GC_OK;
 }
 
@@ -485,6 +552,16 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(gc_correlato
     const int mode = c->use_high_dynamics_resampler ? TRK_MODE_HD_RESAMPLER : TRK_MODE_PLAIN;
     return correlator_run(c, mode, rem_carrier_phase_in_rad, phase_step_rad, 0.0f, rem_code_phase_chips,
         code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples);
+}
+
+gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlator* c,
+    float rem_carrier_phase_in_rad, float phase_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips,
+    int signal_length_samples)
+{
+    GC_REQUIRE(c, "gc_correlator_carrier_wipeoff_multicorrelator_resampler_5: NULL handle");
+    return correlator_run(c, TRK_MODE_COMPLEX_CODE, rem_carrier_phase_in_rad, phase_step_rad, 0.0f, rem_code_phase_chips,
+        code_phase_step_chips, 0.0f, signal_length_samples);
 }
 
 gc_status gc_correlator_free(gc_correlator* c)

@@ -133,14 +133,33 @@ static __device__ __forceinline__ int floor_to_int(float x)
 // Main loop over the chunks [c0, c1) of one (channel, epoch, slice).
 //   WINDOWED: table[] holds code[(lo + k) mod L], indices need no wrap
 //   else    : table[] holds code[0..L), indices are wrapped with the reference's modulo
-template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT>
+//   CC      : the code table holds complex chips (re, im interleaved): Cpu_Multicorrelator's
+//             32fc_xn_resampler_32fc_xn + 32fc_x2_rotator_dot_prod_32fc_xn pair (plain mode only)
+template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false>
 static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
     int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
     float (&accr)[NTAPS], float (&acci)[NTAPS])
 {
     const int tid = threadIdx.x;
-    const float* tl = table - lo;  // windowed lookups index with the unwrapped chip number
+    const float* tl = table - (CC ? 2 * lo : lo);  // windowed lookups index with the unwrapped chip number
+    // one tap, one sample: acc += y * code[i]
+    auto mac = [&](float yr, float yi, int i, float& ar, float& ai) {
+        if (CC)
+            {
+                const f32x2 cv = WINDOWED ? reinterpret_cast<const f32x2*>(tl)[i] : reinterpret_cast<const f32x2*>(table)[posmod(i, L)];
+                ar = fmaf(yr, cv.x, ar);
+                ar = fmaf(-yi, cv.y, ar);
+                ai = fmaf(yr, cv.y, ai);
+                ai = fmaf(yi, cv.x, ai);
+            }
+        else
+            {
+                const float cv = WINDOWED ? tl[i] : table[posmod(i, L)];
+                ar = fmaf(yr, cv, ar);
+                ai = fmaf(yi, cv, ai);
+            }
+    };
 
     // per-chunk advance of the two per-lane rotators: exp(j*TRK_CHUNK*dtheta)
     float wr = 1.0f, wi = 0.0f;
@@ -248,12 +267,8 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
                             }
                         const int i0 = chip_index_hd(step, rate, (unsigned)m0, shifts[0], rem);
                         const int i1 = chip_index_hd(step, rate, (unsigned)m1, shifts[0], rem);
-                        const float cv0 = WINDOWED ? tl[i0] : table[posmod(i0, L)];
-                        const float cv1 = WINDOWED ? tl[i1] : table[posmod(i1, L)];
-                        accr[t] = fmaf(y0r, cv0, accr[t]);
-                        acci[t] = fmaf(y0i, cv0, acci[t]);
-                        accr[t] = fmaf(y1r, cv1, accr[t]);
-                        acci[t] = fmaf(y1i, cv1, acci[t]);
+                        mac(y0r, y0i, i0, accr[t], acci[t]);
+                        mac(y1r, y1i, i1, accr[t], acci[t]);
                     }
             }
         else
@@ -264,12 +279,8 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
                     {
                         const int i0 = floor_to_int((s0 + shifts[t]) - rem);
                         const int i1 = floor_to_int((s1 + shifts[t]) - rem);
-                        const float cv0 = WINDOWED ? tl[i0] : table[posmod(i0, L)];
-                        const float cv1 = WINDOWED ? tl[i1] : table[posmod(i1, L)];
-                        accr[t] = fmaf(y0r, cv0, accr[t]);
-                        acci[t] = fmaf(y0i, cv0, acci[t]);
-                        accr[t] = fmaf(y1r, cv1, accr[t]);
-                        acci[t] = fmaf(y1i, cv1, acci[t]);
+                        mac(y0r, y0i, i0, accr[t], acci[t]);
+                        mac(y1r, y1i, i1, accr[t], acci[t]);
                     }
             }
         if (!HDC)
@@ -340,7 +351,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 // One (channel, epoch, slice): builds the LDS code window, streams the IQ window, reduces the tap sums.
 // Every thread of the 256-thread workgroup must call it; the sum of tap `tid` is returned to the threads
 // with tid < NTAPS (others get 0).  lds: TRK_HDR_FLOATS + lds_table_floats floats of dynamic LDS.
-template <int NTAPS, bool HDR, bool HDC, int FMT>
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
     int lds_table_floats, float* lds)
 {
@@ -448,8 +459,10 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
             monotone = (step >= 0.0f);
         }
     const long long span_ll = (long long)hi - (long long)lo + 1;
-    const bool windowed = monotone && span_ll > 0 && span_ll <= (long long)lds_table_floats;
-    const GC_GLOBAL float* code = (const GC_GLOBAL float*)cd.code;
+    typedef typename std::conditional<CC, f32x2, float>::type chip_t;
+    const bool windowed = monotone && span_ll > 0 && span_ll * (long long)(sizeof(chip_t) / sizeof(float)) <= (long long)lds_table_floats;
+    const GC_GLOBAL chip_t* code = (const GC_GLOBAL chip_t*)cd.code;
+    chip_t* table_c = reinterpret_cast<chip_t*>(table);
     if (windowed)
         {
             const int span = (int)span_ll;
@@ -461,17 +474,17 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
                             int i = cbase + k;  // < 3L: two conditional subtractions instead of a division
                             i = (i >= L) ? i - L : i;
                             i = (i >= L) ? i - L : i;
-                            table[k] = code[i];
+                            table_c[k] = code[i];
                         }
                 }
             else
                 {
-                    for (int k = tid; k < span; k += TRK_THREADS) table[k] = code[(cbase + k) % L];
+                    for (int k = tid; k < span; k += TRK_THREADS) table_c[k] = code[(cbase + k) % L];
                 }
         }
     else
         {
-            for (int k = tid; k < L; k += TRK_THREADS) table[k] = code[k];
+            for (int k = tid; k < L; k += TRK_THREADS) table_c[k] = code[k];
         }
     __syncthreads();
 
@@ -480,9 +493,9 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
     for (int t = 0; t < NTAPS; t++) accr[t] = acci[t] = 0.0f;
 
     if (windowed)
-        trk_loop<NTAPS, HDR, HDC, true, FMT>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, true, FMT, CC>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
     else
-        trk_loop<NTAPS, HDR, HDC, false, FMT>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, false, FMT, CC>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread

@@ -11,7 +11,7 @@ struct TrkChan
 {
     const void* iq;            // IQ base of the channel's RF stream (HBM), samples in the batch's gc_iq_format
     unsigned long long n_iq;   // samples available at iq
-    const float* code;         // code table (HBM), code_len floats
+    const float* code;         // code table (HBM): code_len floats, or code_len (re, im) pairs in TRK_MODE_COMPLEX_CODE
     int code_len;
     int reserved;
     float shifts[GC_MAX_TAPS]; // tap shifts in code samples
@@ -21,11 +21,12 @@ enum
 {
     TRK_MODE_PLAIN = 0,        // resampler_32f_xn + rotator_dot_prod_32fc_xn
     TRK_MODE_HD_RESAMPLER = 1, // high-dynamics resampler + plain rotator (6-argument overload with the flag set)
-    TRK_MODE_HD_FULL = 2       // high-dynamics resampler + high-dynamic rotator
+    TRK_MODE_HD_FULL = 2,      // high-dynamics resampler + high-dynamic rotator
+    TRK_MODE_COMPLEX_CODE = 3  // Cpu_Multicorrelator: resampler_32fc_xn + x2_rotator_dot_prod_32fc_xn (complex chips)
 };
 
 // Enqueues the multicorrelator for n_channels x n_epochs jobs on `st`.
-// lds_table_floats: capacity of the LDS code window (>= longest code_len).
+// lds_table_floats: capacity of the LDS code window in floats (>= longest code_len; twice that for complex chips).
 // partial: workspace of n_channels*n_epochs*n_slices*n_taps float2 (n_slices > 1 only).
 hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const TrkChan* chans,
     const gc_epoch_params* params, float2* out, float2* partial,

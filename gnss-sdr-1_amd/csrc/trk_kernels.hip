@@ -25,7 +25,7 @@
 #ifndef TRK_WAVES
 #define TRK_WAVES 8  // minimum waves per SIMD the register allocator must leave room for (<= 64 VGPRs)
 #endif
-template <int NTAPS, bool HDR, bool HDC, int FMT>
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false>
 __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_kernel(
     const TrkChan* __restrict__ chans, const gc_epoch_params* __restrict__ params,
     float2* __restrict__ out, float2* __restrict__ partial,
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_ke
 
     const TrkChan cd = chans[ch];
     const gc_epoch_params p = params[job];
-    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT>(cd, p, slice, n_slices, lds_table_floats, lds);
+    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC>(cd, p, slice, n_slices, lds_table_floats, lds);
     if (threadIdx.x < NTAPS)
         {
             if (n_slices == 1)
@@ -96,6 +96,10 @@ static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStr
             break;
         case TRK_MODE_HD_FULL:
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, true, true, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
+                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+            break;
+        case TRK_MODE_COMPLEX_CODE:
+            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, FMT, true>), grid, dim3(TRK_THREADS), lds_bytes, st,
                 chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
             break;
         default:

@@ -136,11 +136,15 @@ API = {
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler": (C.c_int, [_vp] + [C.c_float] * 6 + [C.c_int]),
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler_6": (C.c_int, [_vp] + [C.c_float] * 5 + [C.c_int]),
     "gc_correlator_free": (C.c_int, [_vp]),
+    "gc_correlator_set_local_code_and_taps_complex": (C.c_int, [_vp, C.c_int, _fp, _fp]),
+    "gc_correlator_carrier_wipeoff_multicorrelator_resampler_5": (C.c_int, [_vp] + [C.c_float] * 4 + [C.c_int]),
     "gc_epoch_params_fill": (None, [C.POINTER(EpochParams), C.c_uint64] + [C.c_float] * 6 + [C.c_int]),
     "gc_trk_batch_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gc_trk_batch_destroy": (C.c_int, [_vp]),
     "gc_trk_batch_set_code": (C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp]),
     "gc_trk_batch_set_shifts": (C.c_int, [_vp, C.c_int, _fp]),
+    "gc_trk_batch_set_complex_codes": (C.c_int, [_vp, C.c_int]),
+    "gc_trk_batch_set_code_complex": (C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp]),
     "gc_trk_batch_set_input_format": (C.c_int, [_vp, C.c_int]),
     "gc_trk_batch_set_input_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
     "gc_trk_batch_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
@@ -369,6 +373,29 @@ class HipMulticorrelatorRealCodes:
             pass
 
 
+class HipMulticorrelator(HipMulticorrelatorRealCodes):
+    """Image of Cpu_Multicorrelator (complex chips;
+    src/algorithms/tracking/libs/cpu_multicorrelator.h:46-64): init, set_local_code_and_taps,
+    set_input_output_vectors, the 5-argument Carrier_wipeoff_multicorrelator_resampler, free."""
+
+    def set_high_dynamics_resampler(self, use_high_dynamics_resampler):
+        raise AttributeError("Cpu_Multicorrelator has no high-dynamics resampler")
+
+    def set_local_code_and_taps(self, code_length_chips, local_code_in, shifts_chips):
+        assert local_code_in.dtype == np.complex64 and shifts_chips.dtype == np.float32
+        self._keep["code"] = local_code_in
+        self._keep["shifts"] = shifts_chips
+        _check(load_library().gc_correlator_set_local_code_and_taps_complex(self._h, code_length_chips,
+            local_code_in.view(np.float32).ctypes.data_as(_fp), _f32p(shifts_chips)))
+        return True
+
+    def Carrier_wipeoff_multicorrelator_resampler(self, rem_carrier_phase_in_rad, phase_step_rad, rem_code_phase_chips,
+            code_phase_step_chips, signal_length_samples):
+        _check(load_library().gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(self._h, rem_carrier_phase_in_rad,
+            phase_step_rad, rem_code_phase_chips, code_phase_step_chips, int(signal_length_samples)))
+        return True
+
+
 class TrackingBatch:
     """gc_trk_batch: all channels of one GPU, many epochs per launch."""
 
@@ -383,6 +410,15 @@ class TrackingBatch:
         shifts = np.ascontiguousarray(shifts_chips, np.float32)
         assert shifts.size == self.n_taps
         _check(load_library().gc_trk_batch_set_code(self._h, ch, _f32p(code), code.size, _f32p(shifts)))
+
+    def set_complex_codes(self, on=True):
+        _check(load_library().gc_trk_batch_set_complex_codes(self._h, int(bool(on))))
+
+    def set_code_complex(self, ch, code, shifts_chips):
+        code = np.ascontiguousarray(code, np.complex64)
+        shifts = np.ascontiguousarray(shifts_chips, np.float32)
+        assert shifts.size == self.n_taps
+        _check(load_library().gc_trk_batch_set_code_complex(self._h, ch, code.view(np.float32).ctypes.data_as(_fp), code.size, _f32p(shifts)))
 
     def set_shifts(self, ch, shifts_chips):
         shifts = np.ascontiguousarray(shifts_chips, np.float32)

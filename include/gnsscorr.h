@@ -97,6 +97,21 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(gc_correlato
 /* ::free (.cc:173-186) */
 gc_status gc_correlator_free(gc_correlator* c);
 
+/* The same object with COMPLEX chips is the image of Cpu_Multicorrelator
+ * (cpu_multicorrelator.h:46-64; GLONASS L1/L2 and the GPS L1 C-Aid trackers):
+ * volk_gnsssdr_32fc_xn_resampler_32fc_xn (.cc:103-113) followed by
+ * volk_gnsssdr_32fc_x2_rotator_dot_prod_32fc_xn (.cc:116-130).  It has no
+ * carrier-rate / code-rate arguments and no high-dynamics variant.
+ * local_code_in_iq: code_length_chips (re, im) pairs, pointer retained. */
+gc_status gc_correlator_set_local_code_and_taps_complex(gc_correlator* c, int code_length_chips,
+    const float* local_code_in_iq, float* shifts_chips);
+/* Cpu_Multicorrelator::Carrier_wipeoff_multicorrelator_resampler, 5 arguments
+ * (cpu_multicorrelator.cc:116-130); GC_ERR_STATE unless the code is complex. */
+gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlator* c,
+    float rem_carrier_phase_in_rad, float phase_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips,
+    int signal_length_samples);
+
 /* ------------------------------------------------------------------------ */
 /* Level 2 -- batched tracking engine: all channels of a GPU, many epochs,    */
 /* one launch; IQ, parameters and results resident in HBM.                    */
@@ -147,6 +162,13 @@ gc_status gc_trk_batch_destroy(gc_trk_batch* b);
 gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int code_length,
     const float* shifts_chips);
 gc_status gc_trk_batch_set_shifts(gc_trk_batch* b, int ch, const float* shifts_chips);
+/* Complex chips for every channel of the batch (Cpu_Multicorrelator,
+ * cpu_multicorrelator.cc:82-130): switch the batch with set_complex_codes(b, 1)
+ * (drops the codes loaded so far; not available with high_dyn; max_code_length
+ * <= 7936), then load code_length (re, im) pairs per channel. */
+gc_status gc_trk_batch_set_complex_codes(gc_trk_batch* b, int on);
+gc_status gc_trk_batch_set_code_complex(gc_trk_batch* b, int ch, const float* code_iq, int code_length,
+    const float* shifts_chips);
 /* Sample format of every channel's IQ buffer (default GC_IQ_F32). */
 gc_status gc_trk_batch_set_input_format(gc_trk_batch* b, int iq_format);
 /* Points channel `ch` at its IQ samples in HBM (n_samples complex samples of the batch's format,

@@ -158,6 +158,70 @@ void orc_rotator_dot_prod_high_dyn(float* result, const float* in, const float p
     phase[1] = pi;
 }
 
+/* ---- complex-code correlator (Cpu_Multicorrelator) ------------------------ */
+
+void orc_resampler_cc(float* res_out, const float* code_iq, float rem, float step, const float* shifts,
+    uint32_t L, int n_taps, uint32_t N)
+{
+    /* volk_gnsssdr_32fc_xn_resampler_32fc_xn.h:74-91: the chip index expression is the one of the
+     * real-code resampler (…32f_xn_resampler_32f_xn.h:77-94); only the gathered element is complex */
+    for (int t = 0; t < n_taps; t++)
+        {
+            for (uint32_t n = 0; n < N; n++)
+                {
+                    int i = (int)floor(step * (float)n + shifts[t] - rem);
+                    if (i < 0) i += (int)L * (abs(i) / L + 1);
+                    i = i % L;
+                    res_out[2 * ((size_t)t * N + n)] = code_iq[2 * i];
+                    res_out[2 * ((size_t)t * N + n) + 1] = code_iq[2 * i + 1];
+                }
+        }
+}
+
+void orc_rotator_dot_prod_cc(float* result, const float* in, const float phase_inc[2],
+    float phase[2], const float* in_a, uint32_t lda, int n_taps, uint32_t N)
+{
+    /* volk_gnsssdr_32fc_x2_rotator_dot_prod_32fc_xn.h:80-111 */
+    float pr = phase[0], pi = phase[1];
+    for (int t = 0; t < n_taps; t++) result[2 * t] = result[2 * t + 1] = 0.0f;
+    for (uint32_t n = 0; n < N; n++)
+        {
+            float tr, ti;
+            cmulf(&tr, &ti, in[2 * n], in[2 * n + 1], pr, pi); /* tmp32_1 = in * phase (:90) */
+            if (n % 256 == 0)
+                { /* (:93-101) */
+                    float h = hypotf(pr, pi);
+                    pr = pr / h;
+                    pi = pi / h;
+                }
+            float nr, ni;
+            cmulf(&nr, &ni, pr, pi, phase_inc[0], phase_inc[1]); /* (:104) */
+            pr = nr;
+            pi = ni;
+            for (int t = 0; t < n_taps; t++)
+                { /* result += tmp32_1 * in_a[t][n]  (:105-109) */
+                    float cr, ci;
+                    cmulf(&cr, &ci, tr, ti, in_a[2 * ((size_t)t * lda + n)], in_a[2 * ((size_t)t * lda + n) + 1]);
+                    result[2 * t] += cr;
+                    result[2 * t + 1] += ci;
+                }
+        }
+    phase[0] = pr;
+    phase[1] = pi;
+}
+
+void orc_multicorrelator_cc(float* corr_out, const float* sig_in, const float* code_iq,
+    uint32_t L, const float* shifts, int n_taps,
+    float rem_carr, float phase_step, float rem_code, float code_step, uint32_t N, float* scratch)
+{
+    /* cpu_multicorrelator.cc:103-130 */
+    orc_resampler_cc(scratch, code_iq, rem_code, code_step, shifts, L, n_taps, N);
+    float phase[2] = {cosf(rem_carr), -sinf(rem_carr)};
+    float complex e = cexpf(0.0f - I * phase_step);
+    float inc[2] = {crealf(e), cimagf(e)};
+    orc_rotator_dot_prod_cc(corr_out, sig_in, inc, phase, scratch, N, n_taps, N);
+}
+
 void orc_multicorrelator(float* corr_out, const float* sig_in, const float* code,
     uint32_t L, const float* shifts, int n_taps,
     float rem_carr, float phase_step, float phase_rate_step,

@@ -73,6 +73,19 @@ void orc_multicorrelator(float* corr_out, const float* sig_in, const float* code
     float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
     uint32_t N, int high_dyn, float* scratch);
 
+/* Cpu_Multicorrelator (complex chips; tracking/libs/cpu_multicorrelator.cc:103-130):
+ * volk_gnsssdr_32fc_xn_resampler_32fc_xn_generic (…32fc_xn_resampler_32fc_xn.h:74-91), then
+ * volk_gnsssdr_32fc_x2_rotator_dot_prod_32fc_xn_generic (…32fc_x2_rotator_dot_prod_32fc_xn.h:80-111).
+ * code_iq: L (re, im) pairs; res_out / in_a: tap-major n_taps*N complex; scratch: 2*n_taps*N floats. */
+void orc_resampler_cc(float* res_out, const float* code_iq, float rem_code_phase_chips,
+    float code_phase_step_chips, const float* shifts_chips, uint32_t code_length_chips, int n_taps, uint32_t N);
+void orc_rotator_dot_prod_cc(float* result, const float* in, const float phase_inc[2],
+    float phase[2], const float* in_a, uint32_t lda, int n_taps, uint32_t N);
+void orc_multicorrelator_cc(float* corr_out, const float* sig_in, const float* code_iq,
+    uint32_t code_length_chips, const float* shifts_chips, int n_taps,
+    float rem_carrier_phase_rad, float phase_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, uint32_t N, float* scratch);
+
 /* ---- PRN generators -------------------------------------------------------- */
 
 /* gps_l1_ca_code_gen_int (algorithms/libs/gps_sdr_signal_processing.cc:37-116) */

@@ -87,6 +87,8 @@ class Oracle:
         L.orc_resampler_high_dyn.argtypes = [c_int32_p, c_float_p, c_float_p, C.c_float, C.c_float, C.c_float, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_rotator_dot_prod.argtypes = [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_multicorrelator.argtypes = [c_float_p, c_float_p, c_float_p, C.c_uint32, c_float_p, C.c_int] + [C.c_float] * 6 + [C.c_uint32, C.c_int, c_float_p]
+        L.orc_resampler_cc.argtypes = [c_float_p, c_float_p, C.c_float, C.c_float, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
+        L.orc_multicorrelator_cc.argtypes = [c_float_p, c_float_p, c_float_p, C.c_uint32, c_float_p, C.c_int] + [C.c_float] * 4 + [C.c_uint32, c_float_p]
         L.orc_gps_l1_ca_code.argtypes = [c_int32_p, C.c_int32, C.c_uint32]
         L.orc_gps_l1_ca_code_sampled.argtypes = [c_float_p, C.c_uint32, C.c_int32, C.c_uint32]
         L.orc_gps_l1_ca_code_sampled.restype = C.c_int32
@@ -130,6 +132,28 @@ class Oracle:
         self.lib.orc_multicorrelator(out.view(np.float32).ctypes.data_as(c_float_p), sig.view(np.float32).ctypes.data_as(c_float_p),
             _fp(code), len(code), _fp(shifts), len(shifts), rem_carr, phase_step, phase_rate_step,
             rem_code, code_step, code_rate_step, N, int(high_dyn), _fp(scratch))
+        return out
+
+    def resampler_cc(self, code, rem, step, shifts, N):
+        """volk_gnsssdr_32fc_xn_resampler_32fc_xn_generic: (n_taps, N) complex replica."""
+        code = np.ascontiguousarray(code, np.complex64)
+        shifts = np.ascontiguousarray(shifts, np.float32)
+        res = np.empty((len(shifts), N), np.complex64)
+        self.lib.orc_resampler_cc(res.view(np.float32).ctypes.data_as(c_float_p), code.view(np.float32).ctypes.data_as(c_float_p),
+            rem, step, _fp(shifts), len(code), len(shifts), N)
+        return res
+
+    def multicorrelator_cc(self, sig, code, shifts, rem_carr, phase_step, rem_code, code_step, N):
+        """Cpu_Multicorrelator::Carrier_wipeoff_multicorrelator_resampler (complex chips)."""
+        sig = np.ascontiguousarray(sig, np.complex64)
+        code = np.ascontiguousarray(code, np.complex64)
+        shifts = np.ascontiguousarray(shifts, np.float32)
+        assert sig.size >= N
+        out = np.zeros(len(shifts), np.complex64)
+        scratch = np.empty(2 * len(shifts) * N, np.float32)
+        self.lib.orc_multicorrelator_cc(out.view(np.float32).ctypes.data_as(c_float_p), sig.view(np.float32).ctypes.data_as(c_float_p),
+            code.view(np.float32).ctypes.data_as(c_float_p), len(code), _fp(shifts), len(shifts), rem_carr, phase_step,
+            rem_code, code_step, N, _fp(scratch))
         return out
 
     # -- codes --------------------------------------------------------------
@@ -247,6 +271,7 @@ class Ref:
         L.ref_resampler_generic.argtypes = [pp, c_float_p, C.c_float, C.c_float, c_float_p, C.c_uint, C.c_int, C.c_uint]
         L.ref_resampler_u_avx.argtypes = L.ref_resampler_generic.argtypes
         L.ref_resampler_high_dyn_generic.argtypes = [pp, c_float_p, C.c_float, C.c_float, C.c_float, c_float_p, C.c_uint, C.c_int, C.c_uint]
+        L.ref_resampler_cc_generic.argtypes = L.ref_resampler_generic.argtypes
         L.ref_sincos_generic.argtypes = [c_float_p, C.c_float, c_float_p, C.c_uint]
         L.ref_index_max_generic.argtypes = [c_float_p, C.c_uint]
         L.ref_index_max_generic.restype = C.c_uint
@@ -270,6 +295,16 @@ class Ref:
             self.lib.ref_resampler_u_avx(rows, _fp(code), rem, step, _fp(shifts), len(code), nt, N)
         else:
             self.lib.ref_resampler_generic(rows, _fp(code), rem, step, _fp(shifts), len(code), nt, N)
+        return res[:, :N].copy()
+
+    def resampler_cc(self, code, rem, step, shifts, N):
+        """volk_gnsssdr_32fc_xn_resampler_32fc_xn_generic of the reference: (n_taps, N) complex."""
+        code = np.ascontiguousarray(code, np.complex64)
+        shifts = np.ascontiguousarray(shifts, np.float32).copy()
+        nt = len(shifts)
+        res = np.zeros((nt, N + 16), np.complex64)
+        rows = (c_float_p * nt)(*[res[t].view(np.float32).ctypes.data_as(c_float_p) for t in range(nt)])
+        self.lib.ref_resampler_cc_generic(rows, code.view(np.float32).ctypes.data_as(c_float_p), rem, step, _fp(shifts), len(code), nt, N)
         return res[:, :N].copy()
 
     def sincos(self, phase_inc, N, phase0=0.0):

@@ -74,7 +74,7 @@ def main():
     out = {}
     # ---- resampler chip indices from the compiled reference kernels ----
     cases = resampler_cases()
-    store = {"n_cases": np.int32(len(cases))}
+    store = {"n_cases": np.int32(len(cases)), "complex_chip_resampler_checked": np.int32(1)}
     for i, c in enumerate(cases):
         ramp = np.arange(c["L"], dtype=np.float32)
         idx = ref.resampler(ramp, c["rem"], c["step"], c["shifts"], c["N"]).astype(np.int16)
@@ -86,6 +86,12 @@ def main():
             c["rate"] = np.float32(np.nan)
         else:
             idx_hd = ref.resampler(ramp, c["rem"], c["step"], c["shifts"], c["N"], rate=c["rate"]).astype(np.int16)
+        # the complex-chip resampler (Cpu_Multicorrelator) of the reference walks the same indices:
+        # the vectors below therefore pin both
+        cramp = (ramp + 1j * (c["L"] - ramp)).astype(np.complex64)
+        rcc = ref.resampler_cc(cramp, c["rem"], c["step"], c["shifts"], c["N"])
+        assert (rcc.real.astype(np.int16) == idx).all() and (rcc.imag.astype(np.int16) == c["L"] - idx).all()
+        assert (orc.resampler_cc(cramp, c["rem"], c["step"], c["shifts"], c["N"]) == rcc).all()
         # the oracle restatement must agree bit for bit before anything is written
         assert (orc.resampler_indices(c["rem"], c["step"], c["shifts"], c["L"], c["N"]) == idx).all()
         if c["N"] >= 16:

@@ -28,6 +28,20 @@ def test_resampler_chip_indices_match_compiled_reference(oracle):
             assert np.array_equal(got, z["c%d_idx_hd" % i].astype(np.int32)), "hd case %d" % i
 
 
+def test_complex_chip_resampler_walks_the_same_indices(oracle):
+    """make_golden.py asserted that the reference's volk_gnsssdr_32fc_xn_resampler_32fc_xn_generic
+    (Cpu_Multicorrelator) gathers exactly the indices stored for the real-code resampler."""
+    z = np.load(os.path.join(G, "ref_resampler.npz"))
+    assert int(z["complex_chip_resampler_checked"]) == 1
+    for i in range(int(z["n_cases"])):
+        L, N = (int(v) for v in z["c%d_params" % i])
+        rem, step, _ = (np.float32(v) for v in z["c%d_f" % i])
+        ramp = np.arange(L, dtype=np.float32)
+        got = oracle.resampler_cc((ramp + 1j * (L - ramp)).astype(np.complex64), rem, step, z["c%d_shifts" % i], N)
+        idx = z["c%d_idx" % i].astype(np.int32)
+        assert np.array_equal(got.real.astype(np.int32), idx) and np.array_equal(got.imag.astype(np.int32), L - idx), "case %d" % i
+
+
 def test_prn_generators_match_compiled_reference(oracle):
     z = np.load(os.path.join(G, "ref_codes.npz"))
     for k, prn in enumerate(z["gps_prn"]):

@@ -18,6 +18,7 @@
 // |.|^2 + non-coherent accumulation + row maximum into the column epilogue.
 #include "acq_kernels.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #define ACQ_THREADS 256
@@ -110,6 +111,82 @@ static __device__ __forceinline__ void dft8(float2* a)
     a[7] = csub(e[3], o3);
 }
 
+// a * (c -+ j*s): multiplication by the constant exp(-+j*phi), c = cos(phi), s = sin(phi)
+template <bool INV>
+static __device__ __forceinline__ float2 cmul_const(float2 a, float c, float sn)
+{
+    return INV ? make_float2(fmaf(a.x, c, -(a.y * sn)), fmaf(a.y, c, a.x * sn))
+               : make_float2(fmaf(a.x, c, a.y * sn), fmaf(a.y, c, -(a.x * sn)));
+}
+template <bool INV>
+static __device__ __forceinline__ void dft10(float2* a)
+{
+    // 10 = 2 x 5 (decimation in time): X[k] = E[k] + w10^k O[k], X[k+5] = E[k] - w10^k O[k]
+    float2 e[5] = {a[0], a[2], a[4], a[6], a[8]};
+    float2 o[5] = {a[1], a[3], a[5], a[7], a[9]};
+    dft5<INV>(e);
+    dft5<INV>(o);
+    o[1] = cmul_const<INV>(o[1], 0.80901699437494742410f, 0.58778525229247312917f);
+    o[2] = cmul_const<INV>(o[2], 0.30901699437494742410f, 0.95105651629515357212f);
+    o[3] = cmul_const<INV>(o[3], -0.30901699437494742410f, 0.95105651629515357212f);
+    o[4] = cmul_const<INV>(o[4], -0.80901699437494742410f, 0.58778525229247312917f);
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        {
+            a[k] = cadd(e[k], o[k]);
+            a[k + 5] = csub(e[k], o[k]);
+        }
+}
+template <bool INV>
+static __device__ __forceinline__ void dft16(float2* a)
+{
+    // 16 = 4 x 4: F_r = DFT4 of x[4*n1 + r]; X[k1 + 4*k2] = DFT4 over r of w16^(r*k1) F_r[k1]
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    float2 f[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        {
+            f[r][0] = a[r];
+            f[r][1] = a[4 + r];
+            f[r][2] = a[8 + r];
+            f[r][3] = a[12 + r];
+            dft4<INV>(f[r]);
+        }
+    // k1 = 0: no twiddles
+    {
+        float2 g[4] = {f[0][0], f[1][0], f[2][0], f[3][0]};
+        dft4<INV>(g);
+        a[0] = g[0];
+        a[4] = g[1];
+        a[8] = g[2];
+        a[12] = g[3];
+    }
+    {
+        float2 g[4] = {f[0][1], cmul_const<INV>(f[1][1], c1, s1), cmul_const<INV>(f[2][1], h, h), cmul_const<INV>(f[3][1], s1, c1)};
+        dft4<INV>(g);
+        a[1] = g[0];
+        a[5] = g[1];
+        a[9] = g[2];
+        a[13] = g[3];
+    }
+    {
+        float2 g[4] = {f[0][2], cmul_const<INV>(f[1][2], h, h), mul_mj<INV>(f[2][2]), cmul_const<INV>(f[3][2], -h, h)};
+        dft4<INV>(g);
+        a[2] = g[0];
+        a[6] = g[1];
+        a[10] = g[2];
+        a[14] = g[3];
+    }
+    {
+        float2 g[4] = {f[0][3], cmul_const<INV>(f[1][3], s1, c1), cmul_const<INV>(f[2][3], -h, h), cmul_const<INV>(f[3][3], -c1, -s1)};
+        dft4<INV>(g);
+        a[3] = g[0];
+        a[7] = g[1];
+        a[11] = g[2];
+        a[15] = g[3];
+    }
+}
+
 template <int R, bool INV>
 static __device__ __forceinline__ void dftR(float2* a)
 {
@@ -118,6 +195,8 @@ static __device__ __forceinline__ void dftR(float2* a)
     if (R == 4) dft4<INV>(a);
     if (R == 5) dft5<INV>(a);
     if (R == 8) dft8<INV>(a);
+    if (R == 10) dft10<INV>(a);
+    if (R == 16) dft16<INV>(a);
 }
 
 // ---- one Stockham stage of the LDS row FFT ----
@@ -130,7 +209,7 @@ static __device__ __forceinline__ void lds_stage(const float2* __restrict__ x, f
     const float2* __restrict__ twf, int N2, int m, int s)
 {
     const int nb = N2 / R;
-    for (int u = threadIdx.x; u < nb; u += ACQ_THREADS)
+    for (int u = threadIdx.x; u < nb; u += blockDim.x)
         {
             const int r = u % s, q = u / s;
             float2 w[R];
@@ -154,7 +233,7 @@ static __device__ void lds_stage_generic(const float2* __restrict__ x, float2* _
 {
     const int nb = N2 / R;
     const int wR = N2 / R;  // w_R^e = w_N2^(e*N2/R)
-    for (int u = threadIdx.x; u < nb; u += ACQ_THREADS)
+    for (int u = threadIdx.x; u < nb; u += blockDim.x)
         {
             const int r = u % s, q = u / s;
             for (int k = 0; k < R; k++)
@@ -191,11 +270,11 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
     if (B)
         {
             const float2* bb = B + (size_t)((cell / mapB.div) % mapB.mod) * N + row;
-            for (int i = threadIdx.x; i < N2; i += ACQ_THREADS) buf0[i] = cmul(a[i], bb[i]);
+            for (int i = threadIdx.x; i < N2; i += blockDim.x) buf0[i] = cmul(a[i], bb[i]);
         }
     else
         {
-            for (int i = threadIdx.x; i < N2; i += ACQ_THREADS) buf0[i] = a[i];
+            for (int i = threadIdx.x; i < N2; i += blockDim.x) buf0[i] = a[i];
         }
     __syncthreads();
     float2* src = buf0;
@@ -213,6 +292,8 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
                 case 4: lds_stage<4, INV>(src, dst, twf, N2, m, s); break;
                 case 5: lds_stage<5, INV>(src, dst, twf, N2, m, s); break;
                 case 8: lds_stage<8, INV>(src, dst, twf, N2, m, s); break;
+                case 10: lds_stage<10, INV>(src, dst, twf, N2, m, s); break;
+                case 16: lds_stage<16, INV>(src, dst, twf, N2, m, s); break;
                 default: lds_stage_generic<INV>(src, dst, twp, N2, R, m, s); break;
                 }
             __syncthreads();
@@ -226,7 +307,7 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
     // T[k1][n2] so that a row reads it with unit stride
     float2* q = Q + (size_t)cell * N + row;
     const float2* wrow = wN + row;
-    for (int i = threadIdx.x; i < N2; i += ACQ_THREADS)
+    for (int i = threadIdx.x; i < N2; i += blockDim.x)
         {
             float2 v = src[i];
             if (k1 > 0)
@@ -236,6 +317,255 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_rows_kernel(AcqFftPlan plan,
                 }
             q[i] = v;
         }
+}
+
+// ---- rows pass, packed form ----
+// Several rows per 256-thread workgroup so that every stage has about 256*ITER butterflies to hand out
+// (a single 1000-point row offers 100-200: half of the lanes would idle), radices up to 16 (1000 = 10*10*10:
+// three stages instead of four), the first stage fed straight from global memory and the last one
+// storing straight to global memory through the inter-pass twiddle (no staging copies), and in-place
+// LDS between stages: a thread reads all of its butterflies of a stage into registers, the workgroup
+// synchronises, then the outputs overwrite the same LDS rows (half the LDS of a ping-pong pair, so more
+// workgroups per CU).  The kernel is a template of its stage list (radix and butterflies per thread of
+// every stage): row length, strides and the first/last roles are compile-time constants, and each
+// instantiation holds only its own stages, which keeps it at <= 128 VGPRs (one switch over all radices
+// in one kernel made the register allocator spill).  acq_rows2_registry lists the instantiated
+// stage lists; any other row length runs acq_rows_kernel.
+#ifndef ACQ_ROWS2_WAVES
+#define ACQ_ROWS2_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
+#define ACQ_ROWS2_POINTS 20       // R * ITER: points a thread holds per stage
+#define ACQ_ROWS2_LDS_BYTES 40000 // rows * N2 * 8 per workgroup: four workgroups per CU
+
+struct AcqRows2Args
+{
+    const float2* A;
+    AcqCellMap mapA;
+    const float2* B;
+    AcqCellMap mapB;
+    float2* Q;
+    const float2* wN2;
+    const float2* wN;
+    int n_rows;  // N1 * cells
+    int rpw;     // rows per workgroup
+};
+
+// floor(a / b) for 0 <= a < 2^22 given inv_b = 1.0f / b
+static __device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a + 0.5f) * inv_b); }
+
+// one Stockham stage over the workgroup's rows: current length n = R*M, stride S, N2 = n*S
+template <int R, int ITER, bool INV, int N2, int S, bool FIRST, bool LAST>
+static __device__ __forceinline__ void rows2_stage(const AcqFftPlan& plan, const AcqRows2Args& g, float2* lds,
+    int row0, int nrow, const float2* __restrict__ twf)
+{
+    constexpr int NB = N2 / R;       // butterflies per row
+    constexpr int M = N2 / (S * R);  // sub-transform length after this stage
+    const int N = plan.N, N1 = plan.N1;
+    const int total = nrow * NB;
+    const float inv_n1 = 1.0f / (float)N1;
+    float2 a[ITER][R];
+    int off[ITER];  // where the butterfly's outputs go (LDS index, or offset into Q for the last stage)
+    int twi[ITER];  // where its twiddles start
+    // ---- phase 1: gather the inputs ----
+#pragma unroll
+    for (int it = 0; it < ITER; it++)
+        {
+            const int v = threadIdx.x + it * ACQ_THREADS;
+            off[it] = 0;
+            twi[it] = 0;
+            if (v < total)
+                {
+                    const int row = v / NB;
+                    const int u = v - row * NB;
+                    const int q = u / S;
+                    const int r = u - q * S;
+                    int cell = 0, k1 = 0;
+                    if (FIRST || LAST)
+                        {
+                            const int rowid = row0 + row;
+                            cell = fdiv(rowid, inv_n1);
+                            k1 = rowid - cell * N1;
+                        }
+                    if (FIRST)
+                        {
+                            // S == 1: r = 0, q = u; element j of the butterfly is x[q + M*j]
+                            const int ia = cell - fdiv(cell, 1.0f / (float)g.mapA.mod) * g.mapA.mod;  // mapA.div == 1
+                            const float2* ap = g.A + (size_t)ia * N + (size_t)k1 * N2 + q;
+                            if (g.B)
+                                {
+                                    const int ib = fdiv(cell, 1.0f / (float)g.mapB.div);  // mapB.mod is "infinite"
+                                    const float2* bp = g.B + (size_t)ib * N + (size_t)k1 * N2 + q;
+#pragma unroll
+                                    for (int j = 0; j < R; j++) a[it][j] = cmul(ap[M * j], bp[M * j]);
+                                }
+                            else
+                                {
+#pragma unroll
+                                    for (int j = 0; j < R; j++) a[it][j] = ap[M * j];
+                                }
+                        }
+                    else
+                        {
+                            const float2* x = lds + row * N2 + r + S * q;
+#pragma unroll
+                            for (int j = 0; j < R; j++) a[it][j] = x[S * M * j];
+                        }
+                    if (LAST)
+                        {
+                            // M == 1: q = 0; output k goes to n2 = r + S*k of the row
+                            off[it] = cell * N + k1 * N2 + r;
+                            twi[it] = k1 * N2 + r;
+                        }
+                    else
+                        {
+                            off[it] = row * N2 + r + S * R * q;
+                            twi[it] = q;
+                        }
+                }
+        }
+    if (!FIRST) __syncthreads();  // every input of this stage has left LDS
+    // ---- phase 2: butterflies, twiddles, scatter ----
+#pragma unroll
+    for (int it = 0; it < ITER; it++)
+        {
+            const int v = threadIdx.x + it * ACQ_THREADS;
+            if (v < total)
+                {
+                    float2 tw[R];
+                    if (LAST)
+                        {
+                            // inter-pass twiddle w_N^(k1*n2) (exactly 1 in row 0)
+                            const float2* wp = g.wN + twi[it];
+#pragma unroll
+                            for (int k = 0; k < R; k++) tw[k] = wp[S * k];
+                        }
+                    else
+                        {
+                            tw[0] = make_float2(1.0f, 0.0f);
+#pragma unroll
+                            for (int k = 1; k < R; k++) tw[k] = twf[(k - 1) * M + twi[it]];
+                        }
+                    dftR<R, INV>(a[it]);
+                    if (LAST)
+                        {
+                            float2* qp = g.Q + (size_t)off[it];
+#pragma unroll
+                            for (int k = 0; k < R; k++) qp[S * k] = INV ? cmul_conj(a[it][k], tw[k]) : cmul(a[it][k], tw[k]);
+                        }
+                    else
+                        {
+                            float2* y = lds + off[it];
+                            y[0] = a[it][0];
+#pragma unroll
+                            for (int k = 1; k < R; k++) y[S * k] = INV ? cmul_conj(a[it][k], tw[k]) : cmul(a[it][k], tw[k]);
+                        }
+                }
+        }
+    if (!LAST) __syncthreads();  // outputs visible to the next stage
+}
+
+// stage list: RI = R*16 + ITER per stage, run in order
+template <bool INV, int N2, int S, int F, int... RI>
+struct Rows2Run;
+template <bool INV, int N2, int S, int F>
+struct Rows2Run<INV, N2, S, F>
+{
+    static __device__ __forceinline__ void run(const AcqFftPlan&, const AcqRows2Args&, float2*, int, int) {}
+};
+template <bool INV, int N2, int S, int F, int RI0, int... REST>
+struct Rows2Run<INV, N2, S, F, RI0, REST...>
+{
+    static __device__ __forceinline__ void run(const AcqFftPlan& plan, const AcqRows2Args& g, float2* lds, int row0, int nrow)
+    {
+        constexpr int R = RI0 / 16, ITER = RI0 % 16;
+        rows2_stage<R, ITER, INV, N2, S, F == 0, sizeof...(REST) == 0>(plan, g, lds, row0, nrow, g.wN2 + plan.tw_off[F]);
+        Rows2Run<INV, N2, S * R, F + 1, REST...>::run(plan, g, lds, row0, nrow);
+    }
+};
+template <int... RI>
+struct Rows2Len;
+template <>
+struct Rows2Len<>
+{
+    static constexpr int value = 1;
+};
+template <int RI0, int... REST>
+struct Rows2Len<RI0, REST...>
+{
+    static constexpr int value = (RI0 / 16) * Rows2Len<REST...>::value;
+};
+
+template <bool INV, int... RI>
+__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS2_WAVES) void acq_rows2_kernel(AcqFftPlan plan, AcqRows2Args g)
+{
+    extern __shared__ float2 sm[];
+    const int row0 = blockIdx.x * g.rpw;
+    const int nrow = min(g.rpw, g.n_rows - row0);
+    Rows2Run<INV, Rows2Len<RI...>::value, 1, 0, RI...>::run(plan, g, sm, row0, nrow);
+}
+
+// instantiated stage lists (radix, butterflies per thread), as acq_rows2_config derives them for the row
+// lengths the planner picks for 1/2/4/8 ms blocks at 2 ... 25 Msps (and the power-of-two sizes)
+typedef void (*AcqRows2Fn)(AcqFftPlan, AcqRows2Args);
+struct AcqRows2Entry
+{
+    int n_stages;
+    int ri[4];
+    AcqRows2Fn fwd, inv;
+};
+#define R2(r, i) ((r) * 16 + (i))
+#define ROWS2_ENTRY3(a, b, c) {3, {a, b, c, 0}, &acq_rows2_kernel<false, a, b, c>, &acq_rows2_kernel<true, a, b, c>}
+#define ROWS2_ENTRY4(a, b, c, d) {4, {a, b, c, d}, &acq_rows2_kernel<false, a, b, c, d>, &acq_rows2_kernel<true, a, b, c, d>}
+static const AcqRows2Entry acq_rows2_registry[] = {
+    ROWS2_ENTRY3(R2(10, 2), R2(10, 2), R2(10, 2)),            // 1000: N = 2000 ... 25000
+    ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(4, 4)),             // 1024
+    ROWS2_ENTRY4(R2(10, 2), R2(5, 4), R2(5, 4), R2(5, 4)),    // 1250: N = 2500, 6250, 12500
+    ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(5, 4)),             // 1280: N = 32000
+    ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(8, 2)),             // 2048
+    ROWS2_ENTRY3(R2(16, 1), R2(10, 2), R2(10, 2)),            // 1600: N = 40000
+    ROWS2_ENTRY4(R2(16, 1), R2(5, 4), R2(5, 4), R2(5, 4)),    // 2000: N = 50000
+    ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(10, 1)),            // 2560: N = 64000
+    ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(16, 1)),            // 4096
+    ROWS2_ENTRY4(R2(16, 1), R2(10, 2), R2(5, 4), R2(5, 4)),   // 4000: N = 100000
+    ROWS2_ENTRY4(R2(16, 1), R2(10, 2), R2(3, 4), R2(2, 8)),   // 960: N = 24000
+    ROWS2_ENTRY4(R2(16, 1), R2(10, 2), R2(10, 2), R2(2, 8)),  // 3200: N = 80000
+};
+#undef ROWS2_ENTRY3
+#undef ROWS2_ENTRY4
+
+// rows per workgroup and per-stage butterflies per thread for the packed kernel; false: use acq_rows_kernel
+static bool acq_rows2_config(const AcqFftPlan& plan, int* rpw_out, int* iters)
+{
+    const int radices_ok[] = {2, 3, 4, 5, 8, 10, 16};
+    for (int f = 0; f < plan.n_fac; f++)
+        {
+            bool ok = false;
+            for (int r : radices_ok) ok = ok || (plan.fac[f] == r);
+            if (!ok) return false;
+        }
+    if ((size_t)plan.N2 * sizeof(float2) > 64 * 1024) return false;
+    int rpw = (int)(ACQ_ROWS2_LDS_BYTES / ((size_t)plan.N2 * sizeof(float2)));
+    if (rpw < 1) rpw = 1;
+    if (rpw > 16) rpw = 16;
+    for (; rpw >= 1; rpw--)
+        {
+            bool fits = true;
+            for (int f = 0; f < plan.n_fac && fits; f++)
+                {
+                    const int R = plan.fac[f], nb = plan.N2 / R;
+                    const int need = (rpw * nb + ACQ_THREADS - 1) / ACQ_THREADS;
+                    int it = 1;
+                    while (it < need) it *= 2;
+                    if (it * R > ACQ_ROWS2_POINTS || it > 8) fits = false;
+                    iters[f] = it;
+                }
+            if (fits)
+                {
+                    *rpw_out = rpw;
+                    return true;
+                }
+        }
+    return false;
 }
 
 // ---- register-resident N1-point DFT (Stockham, fully unrolled) ----
@@ -668,7 +998,7 @@ __global__ __launch_bounds__(ACQ_FINAL_THREADS) void acq_final_kernel(AcqFinalAr
 static bool factor_rows(int N2, int* fac, int* n_fac)
 {
     int n = N2, k = 0;
-    const int pref[] = {8, 5, 4, 3, 2};
+    const int pref[] = {16, 10, 8, 5, 4, 3, 2};
     while (n > 1)
         {
             int r = 0;
@@ -779,6 +1109,39 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
     const float2* A, AcqCellMap mapA, const float2* B, AcqCellMap mapB,
     float2* Q, const float2* wN2, const float2* wN)
 {
+    static const bool force_wg = [] {
+        const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
+        return e && std::strcmp(e, "wg") == 0;
+    }();
+    AcqRows2Args g;
+    std::memset(&g, 0, sizeof g);
+    int iters[ACQ_MAX_FACTORS];
+    const AcqRows2Entry* entry = nullptr;
+    if (!force_wg && mapA.div == 1 && (B == nullptr || mapB.mod >= (1 << 30)) && plan.n_fac <= 4 && acq_rows2_config(plan, &g.rpw, iters))
+        {
+            for (const AcqRows2Entry& e : acq_rows2_registry)
+                {
+                    bool same = (e.n_stages == plan.n_fac);
+                    for (int f = 0; f < plan.n_fac && same; f++) same = (e.ri[f] == R2(plan.fac[f], iters[f]));
+                    if (same) entry = &e;
+                }
+        }
+    if (entry)
+        {
+            g.A = A;
+            g.mapA = mapA;
+            g.B = B;
+            g.mapB = mapB;
+            g.Q = Q;
+            g.wN2 = wN2;
+            g.wN = wN;
+            g.n_rows = plan.N1 * n_cells;
+            dim3 grid2((g.n_rows + g.rpw - 1) / g.rpw);
+            const size_t lds2 = (size_t)g.rpw * plan.N2 * sizeof(float2);
+            AcqFftPlan plan_arg = plan;
+            void* args[] = {&plan_arg, &g};
+            return hipLaunchKernel(reinterpret_cast<const void*>(inverse ? entry->inv : entry->fwd), grid2, dim3(ACQ_THREADS), args, lds2, st);
+        }
     dim3 grid(plan.N1, n_cells);
     size_t lds = acq_rows_lds_bytes(plan);
     if (lds > 64 * 1024)
@@ -790,10 +1153,16 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (ea != hipSuccess) return ea;
         }
+    static const int row_threads = [] {
+        const char* e = std::getenv("GNSSCORR_ACQ_ROW_THREADS");
+        int v = e ? std::atoi(e) : 0;
+        return (v == 64 || v == 128 || v == 256) ? v : 0;
+    }();
+    const int nthr = row_threads ? row_threads : ACQ_THREADS;
     if (inverse)
-        hipLaunchKernelGGL(acq_rows_kernel<true>, grid, dim3(ACQ_THREADS), lds, st, plan, A, mapA, B, mapB, Q, wN2, wN);
+        hipLaunchKernelGGL(acq_rows_kernel<true>, grid, dim3(nthr), lds, st, plan, A, mapA, B, mapB, Q, wN2, wN);
     else
-        hipLaunchKernelGGL(acq_rows_kernel<false>, grid, dim3(ACQ_THREADS), lds, st, plan, A, mapA, B, mapB, Q, wN2, wN);
+        hipLaunchKernelGGL(acq_rows_kernel<false>, grid, dim3(nthr), lds, st, plan, A, mapA, B, mapB, Q, wN2, wN);
     return hipGetLastError();
 }
 

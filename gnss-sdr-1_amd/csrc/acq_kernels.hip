@@ -348,6 +348,9 @@ struct AcqRows2Args
     const float2* wN;
     int n_rows;  // N1 * cells
     int rpw;     // rows per workgroup
+    int n_bins;  // cells per satellite (= mapA.mod)
+    int n_sats;  // satellites in this launch; cell = sat * n_bins + bin
+    int n_groups;  // workgroups that have rows
 };
 
 // floor(a / b) for 0 <= a < 2^22 given inv_b = 1.0f / b
@@ -362,7 +365,7 @@ static __device__ __forceinline__ void rows2_stage(const AcqFftPlan& plan, const
     constexpr int M = N2 / (S * R);  // sub-transform length after this stage
     const int N = plan.N, N1 = plan.N1;
     const int total = nrow * NB;
-    const float inv_n1 = 1.0f / (float)N1;
+    const float inv_n1 = 1.0f / (float)N1, inv_ns = 1.0f / (float)g.n_sats;
     float2 a[ITER][R];
     int off[ITER];  // where the butterfly's outputs go (LDS index, or offset into Q for the last stage)
     int twi[ITER];  // where its twiddles start
@@ -379,22 +382,25 @@ static __device__ __forceinline__ void rows2_stage(const AcqFftPlan& plan, const
                     const int u = v - row * NB;
                     const int q = u / S;
                     const int r = u - q * S;
-                    int cell = 0, k1 = 0;
+                    int cell = 0, k1 = 0, bin = 0, sat = 0;
                     if (FIRST || LAST)
                         {
+                            // rows are handed out satellite-fastest: (bin, sat, k1) = digits of the row number,
+                            // so that a run of workgroups shares few bins of A (see the kernel's block mapping)
                             const int rowid = row0 + row;
-                            cell = fdiv(rowid, inv_n1);
-                            k1 = rowid - cell * N1;
+                            const int cl = fdiv(rowid, inv_n1);
+                            k1 = rowid - cl * N1;
+                            bin = fdiv(cl, inv_ns);
+                            sat = cl - bin * g.n_sats;
+                            cell = sat * g.n_bins + bin;
                         }
                     if (FIRST)
                         {
                             // S == 1: r = 0, q = u; element j of the butterfly is x[q + M*j]
-                            const int ia = cell - fdiv(cell, 1.0f / (float)g.mapA.mod) * g.mapA.mod;  // mapA.div == 1
-                            const float2* ap = g.A + (size_t)ia * N + (size_t)k1 * N2 + q;
+                            const float2* ap = g.A + (size_t)bin * N + (size_t)k1 * N2 + q;
                             if (g.B)
                                 {
-                                    const int ib = fdiv(cell, 1.0f / (float)g.mapB.div);  // mapB.mod is "infinite"
-                                    const float2* bp = g.B + (size_t)ib * N + (size_t)k1 * N2 + q;
+                                    const float2* bp = g.B + (size_t)sat * N + (size_t)k1 * N2 + q;
 #pragma unroll
                                     for (int j = 0; j < R; j++) a[it][j] = cmul(ap[M * j], bp[M * j]);
                                 }
@@ -499,7 +505,13 @@ template <bool INV, int... RI>
 __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS2_WAVES) void acq_rows2_kernel(AcqFftPlan plan, AcqRows2Args g)
 {
     extern __shared__ float2 sm[];
-    const int row0 = blockIdx.x * g.rpw;
+    // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs, so the blocks with equal
+    // (blockIdx % 8) share an L2.  Each XCD gets one contiguous eighth of the row groups: a few bins of the
+    // signal spectrum x all code spectra of the launch (~3 MB at N = 25000) instead of everything.
+    const int per_xcd = gridDim.x >> 3;
+    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (group >= g.n_groups) return;
+    const int row0 = group * g.rpw;
     const int nrow = min(g.rpw, g.n_rows - row0);
     Rows2Run<INV, Rows2Len<RI...>::value, 1, 0, RI...>::run(plan, g, sm, row0, nrow);
 }
@@ -518,6 +530,7 @@ struct AcqRows2Entry
 #define ROWS2_ENTRY4(a, b, c, d) {4, {a, b, c, d}, &acq_rows2_kernel<false, a, b, c, d>, &acq_rows2_kernel<true, a, b, c, d>}
 static const AcqRows2Entry acq_rows2_registry[] = {
     ROWS2_ENTRY3(R2(10, 2), R2(10, 2), R2(10, 2)),            // 1000: N = 2000 ... 25000
+    ROWS2_ENTRY3(R2(10, 1), R2(10, 1), R2(10, 1)),            // 1000, at most 2 rows per workgroup
     ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(4, 4)),             // 1024
     ROWS2_ENTRY4(R2(10, 2), R2(5, 4), R2(5, 4), R2(5, 4)),    // 1250: N = 2500, 6250, 12500
     ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(5, 4)),             // 1280: N = 32000
@@ -547,6 +560,11 @@ static bool acq_rows2_config(const AcqFftPlan& plan, int* rpw_out, int* iters)
     int rpw = (int)(ACQ_ROWS2_LDS_BYTES / ((size_t)plan.N2 * sizeof(float2)));
     if (rpw < 1) rpw = 1;
     if (rpw > 16) rpw = 16;
+    static const int rpw_cap = [] {
+        const char* e = std::getenv("GNSSCORR_ACQ_RPW");  // tuning knob: cap on the rows per workgroup
+        return e ? std::atoi(e) : 0;
+    }();
+    if (rpw_cap > 0 && rpw > rpw_cap) rpw = rpw_cap;
     for (; rpw >= 1; rpw--)
         {
             bool fits = true;
@@ -1117,7 +1135,9 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
     std::memset(&g, 0, sizeof g);
     int iters[ACQ_MAX_FACTORS];
     const AcqRows2Entry* entry = nullptr;
-    if (!force_wg && mapA.div == 1 && (B == nullptr || mapB.mod >= (1 << 30)) && plan.n_fac <= 4 && acq_rows2_config(plan, &g.rpw, iters))
+    // the packed kernel understands the engine's cell numbering only: cell = sat * n_bins + bin
+    const bool cell_layout_ok = mapA.div == 1 && n_cells % mapA.mod == 0 && (B == nullptr ? n_cells == mapA.mod : (mapB.div == mapA.mod && mapB.mod >= (1 << 30)));
+    if (!force_wg && cell_layout_ok && plan.n_fac <= 4 && acq_rows2_config(plan, &g.rpw, iters))
         {
             for (const AcqRows2Entry& e : acq_rows2_registry)
                 {
@@ -1136,7 +1156,10 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             g.wN2 = wN2;
             g.wN = wN;
             g.n_rows = plan.N1 * n_cells;
-            dim3 grid2((g.n_rows + g.rpw - 1) / g.rpw);
+            g.n_bins = mapA.mod;
+            g.n_sats = n_cells / mapA.mod;
+            g.n_groups = (g.n_rows + g.rpw - 1) / g.rpw;
+            dim3 grid2((unsigned)((g.n_groups + 7) / 8 * 8));
             const size_t lds2 = (size_t)g.rpw * plan.N2 * sizeof(float2);
             AcqFftPlan plan_arg = plan;
             void* args[] = {&plan_arg, &g};

@@ -7,6 +7,7 @@
 #include "gc_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -129,7 +130,9 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     a->n_blocks = acq_cols_blocks(a->plan);
     // scratch Q: keep a batch of satellites within ~96 MB so that it lives in the Infinity Cache
     size_t per_sat = (size_t)a->n_bins_alloc * N * sizeof(float2);
-    a->sats_per_batch = (int)((96u << 20) / per_sat);
+    size_t q_budget = (size_t)96 << 20;
+    if (const char* e = std::getenv("GNSSCORR_ACQ_Q_MB")) q_budget = (size_t)std::max(1, std::atoi(e)) << 20;
+    a->sats_per_batch = (int)(q_budget / per_sat);
     if (a->sats_per_batch < 1) a->sats_per_batch = 1;
     if (a->sats_per_batch > n_sats) a->sats_per_batch = n_sats;
     size_t q_cells = (size_t)a->sats_per_batch * a->n_bins_alloc;

@@ -208,3 +208,31 @@ def test_cshort_input_block(gctx, oracle):
     _check(r, p.core(xf))
     assert r.indext == 524
     acq.close()
+
+
+# FFT sizes that walk every instantiated stage list of the packed row kernel (acq_rows2_registry in
+# acq_kernels.hip) and the general row kernel (prime radices 11 / 31, or a stage list outside the registry)
+@pytest.mark.parametrize("n", [2048, 5456, 6250, 8184, 12000, 24000, 30000, 32000, 32768, 40000, 50000, 64000, 65536, 80000, 100000])
+def test_fft_sizes_against_oracle(gctx, oracle, n):
+    import gnsscorr
+    from helpers import synth_stream
+    fs = n * 1000
+    chips = oracle.gps_l1_ca_code(9).astype(np.float32)
+    x, truth = synth_stream([chips], fs, n, seed=n, cn0_db_hz=(50.0, 50.0), doppler_max=900.0)
+    c = dict(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=float(n),
+        samples_per_chip=int(np.ceil(np.float32(9.7752e-07) * np.float32(fs))), doppler_max=1000, doppler_step=500)
+    code = oracle.gps_l1_ca_code_sampled(9, fs)
+    assert code.size == n
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, **c)
+    assert (acq.fft_size, acq.num_doppler_bins) == (n, 4)
+    acq.set_local_code(0, code)
+    r = acq.dwell(x)[0]
+    p = oracle.pcps(**c)
+    p.set_local_code(code)
+    q = p.core(x)
+    _check(r, q)
+    expect = (-truth[0]["tau0"] * fs / 1.023e6) % n
+    assert min(abs(r.indext - expect), n - abs(r.indext - expect)) <= n / 1023.0 + 1
+    grid, ref = acq.grid(0), p.grid()
+    assert np.max(np.abs(grid - ref)) <= TOL * ref.max()
+    acq.close()

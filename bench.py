@@ -120,6 +120,28 @@ def cpu_baseline(codes_np, shifts, sample_sig, sample_recs, budget_s):
     return n_done * N_EPOCH / dt / 1e6, n_done, dt
 
 
+def cpu_baseline_threads(codes_np, shifts, sample_sig, sample_recs, budget_s, n_threads, rate_1t):
+    """One thread per channel like the reference's own timing test
+    (cpu_multicorrelator_real_codes_test.cc:126-146); every thread spends its whole budget inside one C call."""
+    import threading
+    from oracle import Oracle
+    orc = Oracle(native=True)
+    n_iter = max(1, int(rate_1t * 1e6 / N_EPOCH * budget_s))  # channel-epochs one thread finishes in budget_s
+    rec = sample_recs[0]
+
+    def work():
+        orc.multicorrelator_repeat(n_iter, sample_sig[rec[0]:], codes_np, shifts, rec[1], rec[2], rec[3], rec[4], N_EPOCH)
+
+    threads = [threading.Thread(target=work) for _ in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    return n_threads * n_iter * N_EPOCH / dt / 1e6, n_threads * n_iter, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -381,6 +403,12 @@ def main():
             cpu = {"value": v, "unit": "Msamples/s", "cores": 1, "kind": "port",
                 "sample": "%d channel-epochs of the same workload (GPS L1 C/A, N=25000, 3 taps) in %.1f s, oracle "
                           "(volk_gnsssdr generic restatement, gcc -O3 -march=native), 1 thread" % (n_done, dt)}
+            # the same port with one thread per channel on every host core this process may use
+            n_thr = max(1, min(len(os.sched_getaffinity(0)), N_CHANNELS))
+            if n_thr > 1:
+                vt, nt, dtt = cpu_baseline_threads(codes[0], shifts, sig0, recs, min(6.0, args.cpu_seconds), n_thr, v)
+                extra["cpu_baseline_all_cores"] = {"value": vt, "unit": "Msamples/s", "cores": n_thr, "kind": "port",
+                    "sample": "%d channel-epochs in %.1f s, one thread per channel" % (nt, dtt)}
 
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")

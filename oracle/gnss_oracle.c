@@ -250,6 +250,22 @@ void orc_multicorrelator(float* corr_out, const float* sig_in, const float* code
         }
 }
 
+/* timing helper for bench.py's multi-thread CPU baseline: n_iter back-to-back calls without
+ * returning to the interpreter (each call rewrites corr_out, so nothing is hoisted) */
+void orc_multicorrelator_repeat(int n_iter, float* corr_out, const float* sig_in, const float* code,
+    uint32_t L, const float* shifts, int n_taps,
+    float rem_carr, float phase_step, float phase_rate_step,
+    float rem_code, float code_step, float code_rate_step,
+    uint32_t N, int high_dyn, float* scratch)
+{
+    for (int i = 0; i < n_iter; i++)
+        {
+            orc_multicorrelator(corr_out, sig_in, code, L, shifts, n_taps, rem_carr + 1e-3f * (float)i, phase_step, phase_rate_step,
+                rem_code, code_step, code_rate_step, N, high_dyn, scratch);
+            __asm__ volatile("" ::: "memory");
+        }
+}
+
 /* ------------------------------------------------------------------------- */
 /* PRN generators                                                             */
 /* ------------------------------------------------------------------------- */

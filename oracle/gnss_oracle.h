@@ -73,6 +73,13 @@ void orc_multicorrelator(float* corr_out, const float* sig_in, const float* code
     float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
     uint32_t N, int high_dyn, float* scratch);
 
+/* n_iter back-to-back orc_multicorrelator calls (timing helper of bench.py's threaded CPU baseline) */
+void orc_multicorrelator_repeat(int n_iter, float* corr_out, const float* sig_in, const float* code,
+    uint32_t code_length_chips, const float* shifts_chips, int n_taps,
+    float rem_carrier_phase_rad, float phase_step_rad, float phase_rate_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    uint32_t N, int high_dyn, float* scratch);
+
 /* Cpu_Multicorrelator (complex chips; tracking/libs/cpu_multicorrelator.cc:103-130):
  * volk_gnsssdr_32fc_xn_resampler_32fc_xn_generic (…32fc_xn_resampler_32fc_xn.h:74-91), then
  * volk_gnsssdr_32fc_x2_rotator_dot_prod_32fc_xn_generic (…32fc_x2_rotator_dot_prod_32fc_xn.h:80-111).

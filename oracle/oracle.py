@@ -87,6 +87,7 @@ class Oracle:
         L.orc_resampler_high_dyn.argtypes = [c_int32_p, c_float_p, c_float_p, C.c_float, C.c_float, C.c_float, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_rotator_dot_prod.argtypes = [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_multicorrelator.argtypes = [c_float_p, c_float_p, c_float_p, C.c_uint32, c_float_p, C.c_int] + [C.c_float] * 6 + [C.c_uint32, C.c_int, c_float_p]
+        L.orc_multicorrelator_repeat.argtypes = [C.c_int] + L.orc_multicorrelator.argtypes
         L.orc_resampler_cc.argtypes = [c_float_p, c_float_p, C.c_float, C.c_float, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_multicorrelator_cc.argtypes = [c_float_p, c_float_p, c_float_p, C.c_uint32, c_float_p, C.c_int] + [C.c_float] * 4 + [C.c_uint32, c_float_p]
         L.orc_gps_l1_ca_code.argtypes = [c_int32_p, C.c_int32, C.c_uint32]
@@ -132,6 +133,17 @@ class Oracle:
         self.lib.orc_multicorrelator(out.view(np.float32).ctypes.data_as(c_float_p), sig.view(np.float32).ctypes.data_as(c_float_p),
             _fp(code), len(code), _fp(shifts), len(shifts), rem_carr, phase_step, phase_rate_step,
             rem_code, code_step, code_rate_step, N, int(high_dyn), _fp(scratch))
+        return out
+
+    def multicorrelator_repeat(self, n_iter, sig, code, shifts, rem_carr, phase_step, rem_code, code_step, N):
+        """n_iter back-to-back multicorrelator calls inside C (GIL released): timing only."""
+        sig = np.ascontiguousarray(sig, np.complex64)
+        code = np.ascontiguousarray(code, np.float32)
+        shifts = np.ascontiguousarray(shifts, np.float32)
+        out = np.zeros(len(shifts), np.complex64)
+        scratch = np.empty(len(shifts) * N, np.float32)
+        self.lib.orc_multicorrelator_repeat(int(n_iter), out.view(np.float32).ctypes.data_as(c_float_p), sig.view(np.float32).ctypes.data_as(c_float_p),
+            _fp(code), len(code), _fp(shifts), len(shifts), rem_carr, phase_step, 0.0, rem_code, code_step, 0.0, N, 0, _fp(scratch))
         return out
 
     def resampler_cc(self, code, rem, step, shifts, N):

@@ -303,18 +303,19 @@ gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz)
     return GC_OK;
 }
 
-static gc_status acq_enqueue(gc_acq* a, const float2* dev_iq_in, hipStream_t st)
+// one dwell of every satellite slot on `st`; the caller holds the context mutex
+static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hipStream_t st)
 {
-    const float2* dev_iq = dev_iq_in;
-    if (a->iq_format != GC_IQ_F32)
+    for (int s = 0; s < a->n_sats; s++)
+        if (!a->code_set[s]) return gc_fail(GC_ERR_STATE, "gc_acq_dwell: satellite slot %d has no local code", s);
+    const float2* dev_iq = static_cast<const float2*>(dev_iq_in);
+    if (iq_format != GC_IQ_F32)
         {
             // d_cshort path of acquisition_core (:676-679): convert the block, then the float search
-            hipError_t ec = acq_launch_convert(st, a->iq_format, dev_iq_in, a->d_cvt, (int)a->consumed);
+            hipError_t ec = acq_launch_convert(st, iq_format, dev_iq_in, a->d_cvt, (int)a->consumed);
             if (ec != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: input conversion failed: %s", hipGetErrorString(ec));
             dev_iq = a->d_cvt;
         }
-    for (int s = 0; s < a->n_sats; s++)
-        if (!a->code_set[s]) return gc_fail(GC_ERR_STATE, "gc_acq_dwell: satellite slot %d has no local code", s);
     const size_t N = a->fft_size;
     const int n_bins = (int)a->n_bins;
     a->dwell_counter++;
@@ -387,7 +388,16 @@ gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream)
     GC_REQUIRE(a && dev_iq, "gc_acq_dwell_enqueue: NULL argument");
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
-    return acq_enqueue(a, static_cast<const float2*>(dev_iq), gc_pick_stream(a->ctx, stream));
+    return acq_enqueue(a, dev_iq, a->iq_format, gc_pick_stream(a->ctx, stream));
+}
+
+// results of the last dwell to the host; the caller holds the context mutex
+static gc_status acq_fetch(gc_acq* a, gc_acq_result* host_results, hipStream_t st)
+{
+    GC_HIP(hipMemcpyAsync(a->h_results, a->d_results, sizeof(gc_acq_result) * a->n_sats, hipMemcpyDeviceToHost, st));
+    GC_HIP(hipStreamSynchronize(st));
+    std::memcpy(host_results, a->h_results, sizeof(gc_acq_result) * a->n_sats);
+    return GC_OK;
 }
 
 gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* stream)
@@ -395,34 +405,32 @@ gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* str
     GC_REQUIRE(a && host_results, "gc_acq_fetch_results: NULL argument");
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
-    hipStream_t st = gc_pick_stream(a->ctx, stream);
-    GC_HIP(hipMemcpyAsync(a->h_results, a->d_results, sizeof(gc_acq_result) * a->n_sats, hipMemcpyDeviceToHost, st));
-    GC_HIP(hipStreamSynchronize(st));
-    std::memcpy(host_results, a->h_results, sizeof(gc_acq_result) * a->n_sats);
-    return GC_OK;
+    return acq_fetch(a, host_results, gc_pick_stream(a->ctx, stream));
 }
 
 gc_status gc_acq_dwell_dev(gc_acq* a, const void* dev_iq, gc_acq_result* host_results, void* stream)
 {
-    gc_status s = gc_acq_dwell_enqueue(a, dev_iq, stream);
+    GC_REQUIRE(a && dev_iq && host_results, "gc_acq_dwell_dev: NULL argument");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = gc_pick_stream(a->ctx, stream);
+    gc_status s = acq_enqueue(a, dev_iq, a->iq_format, st);
     if (s != GC_OK) return s;
-    return gc_acq_fetch_results(a, host_results, stream);
+    return acq_fetch(a, host_results, st);
 }
 
 gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_results)
 {
     GC_REQUIRE(a && host_iq && host_results, "gc_acq_dwell: NULL argument");
-    {
-        gc_device_guard g(a->ctx->device);
-        std::lock_guard<std::mutex> lk(a->ctx->mtx);
-        GC_HIP(hipMemcpyAsync(a->d_in, host_iq, sizeof(float2) * a->consumed, hipMemcpyHostToDevice, a->ctx->stream));
-        GC_HIP(hipStreamSynchronize(a->ctx->stream));
-    }
-    const int fmt = a->iq_format;  // the host entry point takes gr_complex, whatever the device format is
-    a->iq_format = GC_IQ_F32;
-    gc_status s = gc_acq_dwell_dev(a, a->d_in, host_results, nullptr);
-    a->iq_format = fmt;
-    return s;
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = a->ctx->stream;
+    // the host entry point takes gr_complex, whatever the device-side format is; the copy, the search and
+    // the read-back stay under one lock because d_in is also set_local_code's staging buffer
+    GC_HIP(hipMemcpyAsync(a->d_in, host_iq, sizeof(float2) * a->consumed, hipMemcpyHostToDevice, st));
+    gc_status s = acq_enqueue(a, a->d_in, GC_IQ_F32, st);
+    if (s != GC_OK) return s;
+    return acq_fetch(a, host_results, st);
 }
 
 gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid)

@@ -505,6 +505,7 @@ gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, 
     GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_set_input_dev: channel %d out of range", ch);
     GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) & 7) == 0, "gc_trk_loop_set_input_dev: IQ pointer must be 8-byte aligned");
     gc_device_guard g(l->ctx->device);
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
     l->iq[ch] = dev_iq;
     l->n_iq[ch] = n_samples;
     if (l->started[ch])

@@ -21,6 +21,11 @@
  * void* (NULL = the context's own stream).  The library fails loudly
  * (GC_ERR_NO_DEVICE) when no HIP device is usable: there is no CPU fallback.
  *
+ * Threading follows the reference (one correlator / acquisition object per
+ * channel, driven by that channel's thread): a handle is used by one thread at
+ * a time; different handles of one context may be used from different threads
+ * at once (their calls are serialised on the context's mutex and stream).
+ *
  * The C++ classes in gnss-sdr-1_amd/adapter/ (Hip_Multicorrelator_Real_Codes,
  * hip_pcps_acquisition, the TrackingInterface/AcquisitionInterface-shaped
  * adapters) are thin inline wrappers over these entry points; INTEGRATION.md

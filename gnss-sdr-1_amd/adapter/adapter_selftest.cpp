@@ -9,6 +9,7 @@
 //     (complex C/A replica, sizes 2048/4096/8192, step 0.3, rem 0.4, carrier step 0.1, concurrent objects), values asserted.
 // Usage: adapter_selftest <tests/golden directory>.  Needs a GPU (run by pytest -m gpu).
 #include "hip_multicorrelator.h"
+#include "hip_multicorrelator_16sc.h"
 #include "hip_multicorrelator_real_codes.h"
 #include "pcps_acquisition_adapters.h"
 #include <cmath>
@@ -161,6 +162,57 @@ static void test_multicorrelator_complex()
         }
     for (auto& c : pool) EXPECT(c.free(), "free");
     std::printf("complex-chip multicorrelator: 4 concurrent objects x sizes 2048/4096/8192 agree with the float64 sums\n");
+}
+
+static void test_multicorrelator_16sc()
+{
+    // cpu_multicorrelator_16sc_test.cc drives Cpu_Multicorrelator_16sc like the complex test (sizes 2048/4096/8192,
+    // step 0.3, rem 0.4, carrier step 0.1); here with an input whose sums stay inside int16 and values asserted
+    const int N = 8192;
+    float chips[1023];
+    gc_gps_l1_ca_code_gen_float(chips, 1, 0);
+    std::vector<Hip_Multicorrelator_16sc::lv_16sc_t> code(1023), in(2 * N);
+    for (int i = 0; i < 1023; i++) code[i] = Hip_Multicorrelator_16sc::lv_16sc_t(static_cast<int16_t>(chips[i]), 0);
+    unsigned lcg = 99u;
+    for (auto& v : in)
+        {
+            lcg = lcg * 1664525u + 1013904223u;
+            const int a = static_cast<int>((lcg >> 16) % 41u) - 20;
+            lcg = lcg * 1664525u + 1013904223u;
+            v = Hip_Multicorrelator_16sc::lv_16sc_t(static_cast<int16_t>(a), static_cast<int16_t>(static_cast<int>((lcg >> 16) % 41u) - 20));
+        }
+    float shifts[3] = {-0.5f, 0.0f, 0.5f};
+    Hip_Multicorrelator_16sc::lv_16sc_t out[3];
+    Hip_Multicorrelator_16sc mc;
+    EXPECT(mc.init(N, 3), "init");
+    EXPECT(mc.set_input_output_vectors(out, in.data()), "set_input_output_vectors");
+    EXPECT(mc.set_local_code_and_taps(1023, code.data(), shifts), "set_local_code_and_taps");
+    const float carr_step = 0.1f, code_step = 0.3f, rem_code = 0.4f;
+    EXPECT(mc.Carrier_wipeoff_multicorrelator_resampler(0.0f, carr_step, rem_code, code_step, N), "correlate");
+    EXPECT(mc.last_status() == GC_OK, "status %d: %s", mc.last_status(), gc_last_error());
+    // float64 phase, round-to-nearest samples, exact integer sums
+    long want_r[3] = {0, 0, 0}, want_i[3] = {0, 0, 0};
+    for (int n = 0; n < N; n++)
+        {
+            const std::complex<double> y = std::complex<double>(in[n].real(), in[n].imag()) * std::exp(std::complex<double>(0.0, -static_cast<double>(carr_step) * n));
+            const long yr = std::lrint(y.real()), yi = std::lrint(y.imag());
+            for (int t = 0; t < 3; t++)
+                {
+                    int i = static_cast<int>(std::floor(code_step * static_cast<float>(n) + shifts[t] - rem_code));
+                    i = ((i % 1023) + 1023) % 1023;
+                    want_r[t] += yr * static_cast<long>(chips[i]);
+                    want_i[t] += yi * static_cast<long>(chips[i]);
+                }
+        }
+    for (int t = 0; t < 3; t++)
+        {
+            EXPECT(std::labs(want_r[t]) < 30000 && std::labs(want_i[t]) < 30000, "test input saturates");
+            // a float32 phase after 8192 steps of 0.1 rad is ~5e-4 rad off the float64 one: a few samples round the other way
+            EXPECT(std::labs(out[t].real() - want_r[t]) <= 40 && std::labs(out[t].imag() - want_i[t]) <= 40, "16sc tap %d: (%d,%d) vs (%ld,%ld)", t, out[t].real(), out[t].imag(), want_r[t], want_i[t]);
+        }
+    EXPECT(mc.free(), "free");
+    std::printf("16-bit multicorrelator: (%d,%d) (%d,%d) (%d,%d) vs float64-phase sums (%ld,%ld) (%ld,%ld) (%ld,%ld)\n", out[0].real(), out[0].imag(),
+        out[1].real(), out[1].imag(), out[2].real(), out[2].imag(), want_r[0], want_i[0], want_r[1], want_i[1], want_r[2], want_i[2]);
 }
 
 struct CountingFsm : public ChannelFsm
@@ -334,6 +386,7 @@ int main(int argc, char** argv)
         }
     test_multicorrelator();
     test_multicorrelator_complex();
+    test_multicorrelator_16sc();
     test_gps_acquisition(argv[1], false);
     test_gps_acquisition(argv[1], true);
     test_galileo_acquisition(argv[1]);

@@ -49,6 +49,7 @@ struct gc_trk_batch
     int iq_format = GC_IQ_F32;
     int forced_slices = 0;
     bool complex_codes = false;
+    bool sc16 = false;  // Cpu_Multicorrelator_16sc arithmetic: int16 IQ, int16 complex chips, int16 results
     std::vector<TrkChan> h_chans;
     bool chans_dirty = true;
     TrkChan* d_chans = nullptr;
@@ -158,6 +159,7 @@ gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int 
     GC_REQUIRE(code_length > 0 && code_length <= b->max_code_len, "gc_trk_batch_set_code: code_length %d not in 1..%d",
         code_length, b->max_code_len);
     if (b->complex_codes) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code: the batch holds complex codes (gc_trk_batch_set_code_complex)");
+    if (b->sc16) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code: the batch is in 16-bit mode (gc_trk_batch_set_code_16sc)");
     gc_device_guard g(b->ctx->device);
     GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * b->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
     b->h_chans[ch].code_len = code_length;
@@ -169,6 +171,7 @@ gc_status gc_trk_batch_set_complex_codes(gc_trk_batch* b, int on)
     GC_REQUIRE(b, "gc_trk_batch_set_complex_codes: NULL argument");
     const bool want = on != 0;
     if (want == b->complex_codes) return GC_OK;
+    if (want && b->sc16) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_complex_codes: the batch is in 16-bit mode");
     if (want && b->mode != TRK_MODE_PLAIN)
         return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_complex_codes: the complex-code correlator has no high-dynamics variant");
     const int per_chip = want ? 2 : 1;
@@ -208,6 +211,35 @@ gc_status gc_trk_batch_set_code_complex(gc_trk_batch* b, int ch, const float* co
     return gc_trk_batch_set_shifts(b, ch, shifts_chips);
 }
 
+gc_status gc_trk_batch_set_16sc(gc_trk_batch* b, int on)
+{
+    GC_REQUIRE(b, "gc_trk_batch_set_16sc: NULL argument");
+    const bool want = on != 0;
+    if (want == b->sc16) return GC_OK;
+    if (want && b->mode != TRK_MODE_PLAIN)
+        return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_16sc: not available with high dynamics or complex float codes");
+    gc_status s = gc_trk_batch_set_input_format(b, want ? GC_IQ_I16 : GC_IQ_F32);  // drops the registered inputs
+    if (s != GC_OK) return s;
+    for (auto& c : b->h_chans) c.code_len = 0;  // every channel needs its code again (4 bytes per chip either way)
+    b->sc16 = want;
+    b->mode = want ? TRK_MODE_SC16 : TRK_MODE_PLAIN;
+    b->chans_dirty = true;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_code_16sc(gc_trk_batch* b, int ch, const int16_t* code_iq, int code_length, const float* shifts_chips)
+{
+    GC_REQUIRE(b && code_iq && shifts_chips, "gc_trk_batch_set_code_16sc: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_code_16sc: channel %d out of range", ch);
+    GC_REQUIRE(code_length > 0 && code_length <= b->max_code_len, "gc_trk_batch_set_code_16sc: code_length %d not in 1..%d",
+        code_length, b->max_code_len);
+    if (!b->sc16) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code_16sc: call gc_trk_batch_set_16sc(batch, 1) first");
+    gc_device_guard g(b->ctx->device);
+    GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * b->max_code_len, code_iq, sizeof(int16_t) * 2 * code_length, hipMemcpyHostToDevice));
+    b->h_chans[ch].code_len = code_length;
+    return gc_trk_batch_set_shifts(b, ch, shifts_chips);
+}
+
 gc_status gc_trk_batch_set_input_dev(gc_trk_batch* b, int ch, const void* dev_iq, uint64_t n_samples)
 {
     GC_REQUIRE(b && dev_iq, "gc_trk_batch_set_input_dev: NULL argument");
@@ -224,6 +256,7 @@ gc_status gc_trk_batch_set_input_format(gc_trk_batch* b, int iq_format)
 {
     GC_REQUIRE(b, "gc_trk_batch_set_input_format: NULL argument");
     GC_REQUIRE(iq_format == GC_IQ_F32 || iq_format == GC_IQ_I16 || iq_format == GC_IQ_I8, "gc_trk_batch_set_input_format: unknown format %d", iq_format);
+    if (b->sc16 && iq_format != GC_IQ_I16) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_input_format: 16-bit mode correlates lv_16sc_t input only");
     if (iq_format != b->iq_format)
         {
             // pointers registered so far were checked against the old sample size
@@ -330,7 +363,9 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
     GC_HIP(hipMemcpyAsync(b->d_params, host_params, jobs * sizeof(gc_epoch_params), hipMemcpyHostToDevice, st));
     gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len);
     if (s != GC_OK) return s;
-    GC_HIP(hipMemcpyAsync(host_out, b->d_out, jobs * b->n_taps * sizeof(float2), hipMemcpyDeviceToHost, st));
+    // 16-bit mode: n_taps lv_16sc_t (4 bytes) per job instead of n_taps complex floats
+    const size_t out_elem = b->sc16 ? sizeof(short2) : sizeof(float2);
+    GC_HIP(hipMemcpyAsync(host_out, b->d_out, jobs * b->n_taps * out_elem, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
     return GC_OK;
 }
@@ -350,9 +385,18 @@ struct gc_correlator
     const float* local_code_in = nullptr;
     float* shifts_chips = nullptr;
     int code_length_chips = 0;
-    bool complex_code = false;  // local_code_in holds (re, im) pairs: Cpu_Multicorrelator
-    float* corr_out = nullptr;
-    const float* sig_in = nullptr;
+    // what local_code_in points at: float chips (Cpu_Multicorrelator_Real_Codes), (re, im) float pairs
+    // (Cpu_Multicorrelator), or (re, im) int16 pairs with int16 input/output (Cpu_Multicorrelator_16sc)
+    enum CodeKind
+    {
+        CODE_REAL,
+        CODE_COMPLEX,
+        CODE_SC16
+    };
+    CodeKind code_kind = CODE_REAL;
+    float* corr_out = nullptr;      // n_corr complex floats, or n_corr lv_16sc_t when io_16sc
+    const float* sig_in = nullptr;  // complex floats, or lv_16sc_t when io_16sc
+    bool io_16sc = false;
     // device side
     float2* d_sig = nullptr;
     float* d_code = nullptr;
@@ -400,9 +444,15 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     if (!c->local_code_in || !c->shifts_chips) return gc_fail(GC_ERR_STATE, "correlator: set_local_code_and_taps() has not been called");
     if (!c->corr_out || !c->sig_in) return gc_fail(GC_ERR_STATE, "correlator: set_input_output_vectors() has not been called");
     GC_REQUIRE(N >= 0 && N <= c->max_len, "correlator: signal_length_samples %d exceeds init() capacity %d", N, c->max_len);
-    const int per_chip = (mode == TRK_MODE_COMPLEX_CODE) ? 2 : 1;
-    if ((per_chip == 2) != c->complex_code)
-        return gc_fail(GC_ERR_STATE, "correlator: the local code is %s; use the matching Carrier_wipeoff overload", c->complex_code ? "complex" : "real");
+    const int per_chip = (mode == TRK_MODE_COMPLEX_CODE) ? 2 : 1;  // floats (4-byte words) per chip
+    const gc_correlator::CodeKind want_kind = (mode == TRK_MODE_COMPLEX_CODE) ? gc_correlator::CODE_COMPLEX
+                                              : (mode == TRK_MODE_SC16)       ? gc_correlator::CODE_SC16
+                                                                              : gc_correlator::CODE_REAL;
+    if (want_kind != c->code_kind)
+        return gc_fail(GC_ERR_STATE, "correlator: the local code is %s; use the matching setters and Carrier_wipeoff overload",
+            c->code_kind == gc_correlator::CODE_COMPLEX ? "complex float" : c->code_kind == gc_correlator::CODE_SC16 ? "16-bit complex" : "real");
+    const bool sc16 = (mode == TRK_MODE_SC16);
+    if (sc16 != c->io_16sc) return gc_fail(GC_ERR_STATE, "correlator: input/output vectors and local code must both be 16-bit or both float");
     GC_REQUIRE(c->code_length_chips > 0 && per_chip * (c->code_length_chips + 64) <= kMaxLdsTableFloats,
         "correlator: code_length_chips %d not supported (max %d)", c->code_length_chips, kMaxLdsTableFloats / per_chip - 64);
     gc_device_guard g(c->ctx->device);
@@ -428,7 +478,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
             c->code_shadow.assign(c->local_code_in, c->local_code_in + LF);
             GC_HIP(hipMemcpyAsync(c->d_code, c->code_shadow.data(), sizeof(float) * LF, hipMemcpyHostToDevice, st));
         }
-    if (N > 0) GC_HIP(hipMemcpyAsync(c->d_sig, c->sig_in, sizeof(float2) * (size_t)N, hipMemcpyHostToDevice, st));
+    if (N > 0) GC_HIP(hipMemcpyAsync(c->d_sig, c->sig_in, (sc16 ? sizeof(short2) : sizeof(float2)) * (size_t)N, hipMemcpyHostToDevice, st));
     gc_correlator::Staging* s = c->h_stage;
     std::memset(&s->chan, 0, sizeof s->chan);
     s->chan.iq = c->d_sig;
@@ -443,12 +493,13 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     int n_slices = chunks / 2;
     if (n_slices < 1) n_slices = 1;
     if (n_slices > c->partial_slices) n_slices = c->partial_slices;
-    hipError_t e = trk_launch(c->n_corr, mode, GC_IQ_F32, st, &c->d_stage->chan, &c->d_stage->params, c->d_out, c->d_partial, 1, 1,
+    hipError_t e = trk_launch(c->n_corr, mode, sc16 ? GC_IQ_I16 : GC_IQ_F32, st, &c->d_stage->chan, &c->d_stage->params, c->d_out, c->d_partial, 1, 1,
         n_slices, per_chip * (L + 64));
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
-    GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, sizeof(float2) * c->n_corr, hipMemcpyDeviceToHost, st));
+    const size_t out_bytes = (sc16 ? sizeof(short2) : sizeof(float2)) * c->n_corr;
+    GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
-    std::memcpy(c->corr_out, c->h_out, sizeof(float2) * c->n_corr);
+    std::memcpy(c->corr_out, c->h_out, out_bytes);
     return GC_OK;
 }
 
@@ -509,7 +560,7 @@ gc_status gc_correlator_set_local_code_and_taps(gc_correlator* c, int code_lengt
     c->local_code_in = local_code_in;
     c->shifts_chips = shifts_chips;
     c->code_length_chips = code_length_chips;
-    c->complex_code = false;
+    c->code_kind = gc_correlator::CODE_REAL;
     return GC_OK;
 }
 
@@ -520,7 +571,27 @@ gc_status gc_correlator_set_local_code_and_taps_complex(gc_correlator* c, int co
     c->local_code_in = local_code_in_iq;
     c->shifts_chips = shifts_chips;
     c->code_length_chips = code_length_chips;
-    c->complex_code = true;
+    c->code_kind = gc_correlator::CODE_COMPLEX;
+    return GC_OK;
+}
+
+gc_status gc_correlator_set_local_code_and_taps_16sc(gc_correlator* c, int code_length_chips, const int16_t* local_code_in_iq,
+    float* shifts_chips)
+{
+    GC_REQUIRE(c, "gc_correlator_set_local_code_and_taps_16sc: NULL handle");
+    c->local_code_in = reinterpret_cast<const float*>(local_code_in_iq);  // 4 bytes per chip, compared and uploaded as words
+    c->shifts_chips = shifts_chips;
+    c->code_length_chips = code_length_chips;
+    c->code_kind = gc_correlator::CODE_SC16;
+    return GC_OK;
+}
+
+gc_status gc_correlator_set_input_output_vectors_16sc(gc_correlator* c, int16_t* corr_out, const int16_t* sig_in)
+{
+    GC_REQUIRE(c, "gc_correlator_set_input_output_vectors_16sc: NULL handle");
+    c->sig_in = reinterpret_cast<const float*>(sig_in);
+    c->corr_out = reinterpret_cast<float*>(corr_out);
+    c->io_16sc = true;
     return GC_OK;
 }
 
@@ -529,6 +600,7 @@ gc_status gc_correlator_set_input_output_vectors(gc_correlator* c, float* corr_o
     GC_REQUIRE(c, "gc_correlator_set_input_output_vectors: NULL handle");
     c->sig_in = sig_in;
     c->corr_out = corr_out;
+    c->io_16sc = false;
     return GC_OK;
 }
 
@@ -560,7 +632,7 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlato
     int signal_length_samples)
 {
     GC_REQUIRE(c, "gc_correlator_carrier_wipeoff_multicorrelator_resampler_5: NULL handle");
-    return correlator_run(c, TRK_MODE_COMPLEX_CODE, rem_carrier_phase_in_rad, phase_step_rad, 0.0f, rem_code_phase_chips,
+    return correlator_run(c, c->code_kind == gc_correlator::CODE_SC16 ? TRK_MODE_SC16 : TRK_MODE_COMPLEX_CODE, rem_carrier_phase_in_rad, phase_step_rad, 0.0f, rem_code_phase_chips,
         code_phase_step_chips, 0.0f, signal_length_samples);
 }
 

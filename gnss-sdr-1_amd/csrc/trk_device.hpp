@@ -61,6 +61,20 @@ static __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// the same reduction on 32-bit integers (exact, order-independent)
+static __device__ __forceinline__ int wave_sum_i(int v)
+{
+#define GC_DPP_ADDI(ctrl, row_mask, bank_mask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, row_mask, bank_mask, false)
+    GC_DPP_ADDI(0x111, 0xf, 0xf);
+    GC_DPP_ADDI(0x112, 0xf, 0xf);
+    GC_DPP_ADDI(0x114, 0xf, 0xe);
+    GC_DPP_ADDI(0x118, 0xf, 0xc);
+    GC_DPP_ADDI(0x142, 0xa, 0xf);
+    GC_DPP_ADDI(0x143, 0xc, 0xf);
+#undef GC_DPP_ADDI
+    return v;
+}
+
 // exact carrier rotator for sample n: exp(j*(theta0 + n*dtheta [+ e(n)*drate]))
 template <bool HDC>
 static __device__ __forceinline__ void carrier_at(int n, double theta0, double dtheta, double drate,
@@ -135,7 +149,11 @@ static __device__ __forceinline__ int floor_to_int(float x)
 //   else    : table[] holds code[0..L), indices are wrapped with the reference's modulo
 //   CC      : the code table holds complex chips (re, im interleaved): Cpu_Multicorrelator's
 //             32fc_xn_resampler_32fc_xn + 32fc_x2_rotator_dot_prod_32fc_xn pair (plain mode only)
-template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false>
+//   SC16    : Cpu_Multicorrelator_16sc arithmetic (volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn): the rotated
+//             sample is rounded to int16, multiplied with an int16 complex chip (wrapping to int16 like the
+//             reference's lv_16sc_t product) and accumulated in 32-bit integers; the table holds one
+//             (re16, im16) pair per 4-byte word and the accumulators carry integer bit patterns
+template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false, bool SC16 = false>
 static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
     int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
@@ -145,7 +163,18 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     const float* tl = table - (CC ? 2 * lo : lo);  // windowed lookups index with the unwrapped chip number
     // one tap, one sample: acc += y * code[i]
     auto mac = [&](float yr, float yi, int i, float& ar, float& ai) {
-        if (CC)
+        if (SC16)
+            {
+                // yr / yi already hold the rounded int16 sample (as integers in float registers' bits)
+                const int bits = __float_as_int(WINDOWED ? tl[i] : table[posmod(i, L)]);
+                const int cr = (short)(bits & 0xffff), ci = bits >> 16;
+                const int sr = __float_as_int(yr), si = __float_as_int(yi);
+                const int pr = (short)(sr * cr - si * ci);  // lv_16sc_t product: computed in int, stored as int16
+                const int pi = (short)(sr * ci + si * cr);
+                ar = __int_as_float(__float_as_int(ar) + pr);
+                ai = __int_as_float(__float_as_int(ai) + pi);
+            }
+        else if (CC)
             {
                 const f32x2 cv = WINDOWED ? reinterpret_cast<const f32x2*>(tl)[i] : reinterpret_cast<const f32x2*>(table)[posmod(i, L)];
                 ar = fmaf(yr, cv.x, ar);
@@ -245,10 +274,23 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
                 z1i *= g1;
             }
         // ---- wipe-off: y = x * z ----
-        const float y0r = fmaf(xc.x, z0r, -(xc.y * z0i));
-        const float y0i = fmaf(xc.x, z0i, xc.y * z0r);
-        const float y1r = fmaf(xc.z, z1r, -(xc.w * z1i));
-        const float y1i = fmaf(xc.z, z1i, xc.w * z1r);
+        float y0r, y0i, y1r, y1i;
+        if (SC16)
+            {
+                // tmp32 = (float)x * phase with the reference's separate products (…16ic_x2_rotator_dot_prod_16ic_xn.h:93),
+                // tmp16 = (int16_t)rintf(.) (:94)
+                y0r = __int_as_float((int)(short)__float2int_rn(xc.x * z0r - xc.y * z0i));
+                y0i = __int_as_float((int)(short)__float2int_rn(xc.x * z0i + xc.y * z0r));
+                y1r = __int_as_float((int)(short)__float2int_rn(xc.z * z1r - xc.w * z1i));
+                y1i = __int_as_float((int)(short)__float2int_rn(xc.z * z1i + xc.w * z1r));
+            }
+        else
+            {
+                y0r = fmaf(xc.x, z0r, -(xc.y * z0i));
+                y0i = fmaf(xc.x, z0i, xc.y * z0r);
+                y1r = fmaf(xc.z, z1r, -(xc.w * z1i));
+                y1i = fmaf(xc.z, z1i, xc.w * z1r);
+            }
         // ---- code NCO + E/P/L accumulation ----
         if (HDR)
             {
@@ -351,7 +393,8 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 // One (channel, epoch, slice): builds the LDS code window, streams the IQ window, reduces the tap sums.
 // Every thread of the 256-thread workgroup must call it; the sum of tap `tid` is returned to the threads
 // with tid < NTAPS (others get 0).  lds: TRK_HDR_FLOATS + lds_table_floats floats of dynamic LDS.
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false>
+// With SC16 the returned pair holds the two 32-bit integer sums as bit patterns.
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
     int lds_table_floats, float* lds)
 {
@@ -493,9 +536,9 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
     for (int t = 0; t < NTAPS; t++) accr[t] = acci[t] = 0.0f;
 
     if (windowed)
-        trk_loop<NTAPS, HDR, HDC, true, FMT, CC>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
     else
-        trk_loop<NTAPS, HDR, HDC, false, FMT, CC>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread
@@ -503,8 +546,17 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
 #pragma unroll
     for (int t = 0; t < NTAPS; t++)
         {
-            float sr = wave_sum(accr[t]);
-            float si = wave_sum(acci[t]);
+            float sr, si;
+            if (SC16)
+                {
+                    sr = __int_as_float(wave_sum_i(__float_as_int(accr[t])));
+                    si = __int_as_float(wave_sum_i(__float_as_int(acci[t])));
+                }
+            else
+                {
+                    sr = wave_sum(accr[t]);
+                    si = wave_sum(acci[t]);
+                }
             if (lane == 63)
                 {
                     lds[(wave * NTAPS + t) * 2 + 0] = sr;
@@ -519,8 +571,16 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
 #pragma unroll
             for (int w = 0; w < TRK_THREADS / 64; w++)
                 {
-                    sr += lds[(w * NTAPS + tid) * 2 + 0];
-                    si += lds[(w * NTAPS + tid) * 2 + 1];
+                    if (SC16)
+                        {
+                            sr = __int_as_float(__float_as_int(sr) + __float_as_int(lds[(w * NTAPS + tid) * 2 + 0]));
+                            si = __int_as_float(__float_as_int(si) + __float_as_int(lds[(w * NTAPS + tid) * 2 + 1]));
+                        }
+                    else
+                        {
+                            sr += lds[(w * NTAPS + tid) * 2 + 0];
+                            si += lds[(w * NTAPS + tid) * 2 + 1];
+                        }
                 }
             r = make_float2(sr, si);
         }

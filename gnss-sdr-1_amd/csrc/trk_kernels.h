@@ -22,7 +22,9 @@ enum
     TRK_MODE_PLAIN = 0,        // resampler_32f_xn + rotator_dot_prod_32fc_xn
     TRK_MODE_HD_RESAMPLER = 1, // high-dynamics resampler + plain rotator (6-argument overload with the flag set)
     TRK_MODE_HD_FULL = 2,      // high-dynamics resampler + high-dynamic rotator
-    TRK_MODE_COMPLEX_CODE = 3  // Cpu_Multicorrelator: resampler_32fc_xn + x2_rotator_dot_prod_32fc_xn (complex chips)
+    TRK_MODE_COMPLEX_CODE = 3, // Cpu_Multicorrelator: resampler_32fc_xn + x2_rotator_dot_prod_32fc_xn (complex chips)
+    TRK_MODE_SC16 = 4          // Cpu_Multicorrelator_16sc: 16ic_xn_resampler_16ic_xn + 16ic_x2_rotator_dot_prod_16ic_xn
+                               // (GC_IQ_I16 input, one (re16, im16) word per chip, `out` receives n_taps short2)
 };
 
 // Enqueues the multicorrelator for n_channels x n_epochs jobs on `st`.

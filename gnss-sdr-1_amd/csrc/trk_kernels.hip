@@ -25,7 +25,9 @@
 #ifndef TRK_WAVES
 #define TRK_WAVES 8  // minimum waves per SIMD the register allocator must leave room for (<= 64 VGPRs)
 #endif
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false>
+static __device__ __forceinline__ short sat16(int v) { return (short)min(max(v, -32768), 32767); }
+
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false>
 __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_kernel(
     const TrkChan* __restrict__ chans, const gc_epoch_params* __restrict__ params,
     float2* __restrict__ out, float2* __restrict__ partial,
@@ -49,11 +51,16 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_ke
 
     const TrkChan cd = chans[ch];
     const gc_epoch_params p = params[job];
-    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC>(cd, p, slice, n_slices, lds_table_floats, lds);
+    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC, SC16>(cd, p, slice, n_slices, lds_table_floats, lds);
     if (threadIdx.x < NTAPS)
         {
             if (n_slices == 1)
-                out[(size_t)job * NTAPS + threadIdx.x] = r;
+                {
+                    if (SC16)  // lv_16sc_t results: the exact integer sums, saturated once
+                        reinterpret_cast<short2*>(out)[(size_t)job * NTAPS + threadIdx.x] = make_short2(sat16(__float_as_int(r.x)), sat16(__float_as_int(r.y)));
+                    else
+                        out[(size_t)job * NTAPS + threadIdx.x] = r;
+                }
             else
                 partial[((size_t)job * n_slices + slice) * NTAPS + threadIdx.x] = r;
         }
@@ -61,11 +68,23 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_ke
 
 // sums the per-slice partials in slice order (deterministic)
 __global__ void trk_finish_kernel(const float2* __restrict__ partial, float2* __restrict__ out,
-    int n_items /* jobs*n_taps */, int n_taps, int n_slices)
+    int n_items /* jobs*n_taps */, int n_taps, int n_slices, int sc16)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     int job = i / n_taps, t = i % n_taps;
+    if (sc16)
+        {
+            int sr = 0, si = 0;
+            for (int s = 0; s < n_slices; s++)
+                {
+                    float2 v = partial[((size_t)job * n_slices + s) * n_taps + t];
+                    sr += __float_as_int(v.x);
+                    si += __float_as_int(v.y);
+                }
+            reinterpret_cast<short2*>(out)[i] = make_short2(sat16(sr), sat16(si));
+            return;
+        }
     float sr = 0.f, si = 0.f;
     for (int s = 0; s < n_slices; s++)
         {
@@ -100,6 +119,11 @@ static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStr
             break;
         case TRK_MODE_COMPLEX_CODE:
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, FMT, true>), grid, dim3(TRK_THREADS), lds_bytes, st,
+                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+            break;
+        case TRK_MODE_SC16:
+            if (FMT != GC_IQ_I16) return hipErrorInvalidValue;  // lv_16sc_t in, lv_16sc_t out
+            hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, GC_IQ_I16, false, true>), grid, dim3(TRK_THREADS), lds_bytes, st,
                 chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
             break;
         default:
@@ -158,7 +182,7 @@ hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const
         {
             int n_items = n_channels * n_epochs * n_taps;
             hipLaunchKernelGGL(trk_finish_kernel, dim3((n_items + 255) / 256), dim3(256), 0, st,
-                partial, out, n_items, n_taps, n_slices);
+                partial, out, n_items, n_taps, n_slices, mode == TRK_MODE_SC16 ? 1 : 0);
             e = hipGetLastError();
         }
     return e;

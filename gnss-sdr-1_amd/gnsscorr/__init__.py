@@ -120,6 +120,7 @@ assert LOOP_RECORD_DTYPE.itemsize == 112 and C.sizeof(LoopConf) == 144
 # every symbol include/gnsscorr.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 _fp = C.POINTER(C.c_float)
+_i16p = C.POINTER(C.c_int16)
 API = {
     "gc_last_error": (C.c_char_p, []),
     "gc_version": (C.c_char_p, []),
@@ -138,6 +139,8 @@ API = {
     "gc_correlator_free": (C.c_int, [_vp]),
     "gc_correlator_set_local_code_and_taps_complex": (C.c_int, [_vp, C.c_int, _fp, _fp]),
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler_5": (C.c_int, [_vp] + [C.c_float] * 4 + [C.c_int]),
+    "gc_correlator_set_local_code_and_taps_16sc": (C.c_int, [_vp, C.c_int, _i16p, _fp]),
+    "gc_correlator_set_input_output_vectors_16sc": (C.c_int, [_vp, _i16p, _i16p]),
     "gc_epoch_params_fill": (None, [C.POINTER(EpochParams), C.c_uint64] + [C.c_float] * 6 + [C.c_int]),
     "gc_trk_batch_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gc_trk_batch_destroy": (C.c_int, [_vp]),
@@ -145,6 +148,8 @@ API = {
     "gc_trk_batch_set_shifts": (C.c_int, [_vp, C.c_int, _fp]),
     "gc_trk_batch_set_complex_codes": (C.c_int, [_vp, C.c_int]),
     "gc_trk_batch_set_code_complex": (C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp]),
+    "gc_trk_batch_set_16sc": (C.c_int, [_vp, C.c_int]),
+    "gc_trk_batch_set_code_16sc": (C.c_int, [_vp, C.c_int, _i16p, C.c_int, _fp]),
     "gc_trk_batch_set_input_format": (C.c_int, [_vp, C.c_int]),
     "gc_trk_batch_set_input_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
     "gc_trk_batch_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
@@ -396,12 +401,42 @@ class HipMulticorrelator(HipMulticorrelatorRealCodes):
         return True
 
 
+class HipMulticorrelator16sc(HipMulticorrelatorRealCodes):
+    """Image of Cpu_Multicorrelator_16sc (src/algorithms/tracking/libs/cpu_multicorrelator_16sc.h:44-67):
+    lv_16sc_t chips, input and output as int16 arrays of shape (n, 2)."""
+
+    def set_high_dynamics_resampler(self, use_high_dynamics_resampler):
+        raise AttributeError("Cpu_Multicorrelator_16sc has no high-dynamics resampler")
+
+    def set_local_code_and_taps(self, code_length_chips, local_code_in, shifts_chips):
+        assert local_code_in.dtype == np.int16 and local_code_in.shape[-1] == 2 and shifts_chips.dtype == np.float32
+        self._keep["code"] = local_code_in
+        self._keep["shifts"] = shifts_chips
+        _check(load_library().gc_correlator_set_local_code_and_taps_16sc(self._h, code_length_chips,
+            local_code_in.ctypes.data_as(_i16p), _f32p(shifts_chips)))
+        return True
+
+    def set_input_output_vectors(self, corr_out, sig_in):
+        assert corr_out.dtype == np.int16 and sig_in.dtype == np.int16
+        self._keep["out"] = corr_out
+        self._keep["in"] = sig_in
+        _check(load_library().gc_correlator_set_input_output_vectors_16sc(self._h, corr_out.ctypes.data_as(_i16p), sig_in.ctypes.data_as(_i16p)))
+        return True
+
+    def Carrier_wipeoff_multicorrelator_resampler(self, rem_carrier_phase_in_rad, phase_step_rad, rem_code_phase_chips,
+            code_phase_step_chips, signal_length_samples):
+        _check(load_library().gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(self._h, rem_carrier_phase_in_rad,
+            phase_step_rad, rem_code_phase_chips, code_phase_step_chips, int(signal_length_samples)))
+        return True
+
+
 class TrackingBatch:
     """gc_trk_batch: all channels of one GPU, many epochs per launch."""
 
     def __init__(self, ctx, n_channels, n_taps, max_code_length, high_dyn=False):
         self._ctx = ctx
         self.n_channels, self.n_taps = n_channels, n_taps
+        self._sc16 = False
         self._h = _vp()
         _check(load_library().gc_trk_batch_create(ctx._h, n_channels, n_taps, max_code_length, int(high_dyn), C.byref(self._h)))
 
@@ -419,6 +454,16 @@ class TrackingBatch:
         shifts = np.ascontiguousarray(shifts_chips, np.float32)
         assert shifts.size == self.n_taps
         _check(load_library().gc_trk_batch_set_code_complex(self._h, ch, code.view(np.float32).ctypes.data_as(_fp), code.size, _f32p(shifts)))
+
+    def set_16sc(self, on=True):
+        _check(load_library().gc_trk_batch_set_16sc(self._h, int(bool(on))))
+        self._sc16 = bool(on)
+
+    def set_code_16sc(self, ch, code, shifts_chips):
+        code = np.ascontiguousarray(code, np.int16)
+        shifts = np.ascontiguousarray(shifts_chips, np.float32)
+        assert shifts.size == self.n_taps and code.ndim == 2 and code.shape[1] == 2
+        _check(load_library().gc_trk_batch_set_code_16sc(self._h, ch, code.ctypes.data_as(_i16p), code.shape[0], _f32p(shifts)))
 
     def set_shifts(self, ch, shifts_chips):
         shifts = np.ascontiguousarray(shifts_chips, np.float32)
@@ -442,9 +487,13 @@ class TrackingBatch:
 
     def run(self, n_epochs, params):
         """params: structured array (EPOCH_DTYPE) of n_channels*n_epochs records, channel-major.
-        Returns complex64 [n_channels, n_epochs, n_taps]."""
+        Returns complex64 [n_channels, n_epochs, n_taps] (int16 [n_channels, n_epochs, n_taps, 2] in 16-bit mode)."""
         params = np.ascontiguousarray(params, EPOCH_DTYPE)
         assert params.size == self.n_channels * n_epochs
+        if self._sc16:
+            out = np.zeros((self.n_channels, n_epochs, self.n_taps, 2), np.int16)
+            _check(load_library().gc_trk_batch_run(self._h, n_epochs, params.ctypes.data_as(_vp), C.cast(out.ctypes.data, _fp)))
+            return out
         out = np.zeros((self.n_channels, n_epochs, self.n_taps), np.complex64)
         _check(load_library().gc_trk_batch_run(self._h, n_epochs, params.ctypes.data_as(_vp), out.view(np.float32).ctypes.data_as(_fp)))
         return out

@@ -117,6 +117,21 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlato
     float rem_code_phase_chips, float code_phase_step_chips,
     int signal_length_samples);
 
+/* With lv_16sc_t chips, input and output the object is the image of
+ * Cpu_Multicorrelator_16sc (cpu_multicorrelator_16sc.h:44-67; the *_sc C-Aid
+ * trackers): volk_gnsssdr_16ic_xn_resampler_16ic_xn followed by
+ * volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn (.cc:78-103), run with the
+ * 5-argument call above.  Arithmetic: each rotated sample is rounded to int16
+ * (rintf), multiplied with the int16 chip (int16 wrap) and summed.  The sums
+ * are formed exactly in 32 bits and saturated once, which equals the
+ * reference's running saturating sum whenever no intermediate sum leaves the
+ * int16 range; the rounding of a sample can differ by one LSB where the
+ * reference's sequentially rounded float phase puts it on the other side of
+ * x.5.  int16 arrays are (re, im) interleaved. */
+gc_status gc_correlator_set_local_code_and_taps_16sc(gc_correlator* c, int code_length_chips,
+    const int16_t* local_code_in_iq, float* shifts_chips);
+gc_status gc_correlator_set_input_output_vectors_16sc(gc_correlator* c, int16_t* corr_out, const int16_t* sig_in);
+
 /* ------------------------------------------------------------------------ */
 /* Level 2 -- batched tracking engine: all channels of a GPU, many epochs,    */
 /* one launch; IQ, parameters and results resident in HBM.                    */
@@ -173,6 +188,14 @@ gc_status gc_trk_batch_set_shifts(gc_trk_batch* b, int ch, const float* shifts_c
  * <= 7936), then load code_length (re, im) pairs per channel. */
 gc_status gc_trk_batch_set_complex_codes(gc_trk_batch* b, int on);
 gc_status gc_trk_batch_set_code_complex(gc_trk_batch* b, int ch, const float* code_iq, int code_length,
+    const float* shifts_chips);
+/* Cpu_Multicorrelator_16sc arithmetic for every channel of the batch (see
+ * gc_correlator_set_local_code_and_taps_16sc): set_16sc(b, 1) switches the
+ * input format to GC_IQ_I16 and drops codes and inputs loaded so far (not
+ * available with high_dyn); codes are code_length (re16, im16) pairs; the
+ * output of run / run_dev is n_taps lv_16sc_t (4 bytes) per channel-epoch. */
+gc_status gc_trk_batch_set_16sc(gc_trk_batch* b, int on);
+gc_status gc_trk_batch_set_code_16sc(gc_trk_batch* b, int ch, const int16_t* code_iq, int code_length,
     const float* shifts_chips);
 /* Sample format of every channel's IQ buffer (default GC_IQ_F32). */
 gc_status gc_trk_batch_set_input_format(gc_trk_batch* b, int iq_format);

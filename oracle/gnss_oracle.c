@@ -250,6 +250,74 @@ void orc_multicorrelator(float* corr_out, const float* sig_in, const float* code
         }
 }
 
+/* ---- 16-bit correlator (Cpu_Multicorrelator_16sc) ---------------------------- */
+
+static inline int16_t sat_adds16(int16_t x, int16_t y)
+{
+    /* saturation_arithmetic.h:30-38 */
+    int32_t r = (int32_t)x + (int32_t)y;
+    if (r < -32768) r = -32768;
+    if (r > 32767) r = 32767;
+    return (int16_t)r;
+}
+
+void orc_multicorrelator_16sc(int16_t* corr_out, const int16_t* sig_in, const int16_t* code_iq,
+    uint32_t L, const float* shifts, int n_taps,
+    float rem_carr, float phase_step, float rem_code, float code_step, uint32_t N, int32_t* exact_sums)
+{
+    /* cpu_multicorrelator_16sc.cc:78-103: volk_gnsssdr_16ic_xn_resampler_16ic_xn_generic
+     * (…16ic_xn_resampler_16ic_xn.h:74-91, same chip index expression as the float resamplers), then
+     * volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn_generic (…16ic_x2_rotator_dot_prod_16ic_xn.h:80-110).
+     * exact_sums (optional, 2*n_taps): the same products summed without saturation. */
+    float pr = cosf(rem_carr), pi = -sinf(rem_carr);
+    float complex e = cexpf(0.0f - I * phase_step);
+    const float ir = crealf(e), ii = cimagf(e);
+    int16_t accr[16], acci[16];
+    int32_t exr[16], exi[16];
+    for (int t = 0; t < n_taps; t++) accr[t] = acci[t] = 0, exr[t] = exi[t] = 0;
+    for (uint32_t n = 0; n < N; n++)
+        {
+            /* tmp32 = (float)in * phase; tmp16 = (int16_t)rintf(.)  (:92-94) */
+            float tr, ti;
+            cmulf(&tr, &ti, (float)sig_in[2 * n], (float)sig_in[2 * n + 1], pr, pi);
+            const int16_t yr = (int16_t)rintf(tr), yi = (int16_t)rintf(ti);
+            if (n % 256 == 0)
+                { /* (:97-105) */
+                    float h = hypotf(pr, pi);
+                    pr = pr / h;
+                    pi = pi / h;
+                }
+            float nr, ni;
+            cmulf(&nr, &ni, pr, pi, ir, ii); /* (:107) */
+            pr = nr;
+            pi = ni;
+            for (int t = 0; t < n_taps; t++)
+                {
+                    int i = (int)floor(code_step * (float)n + shifts[t] - rem_code);
+                    if (i < 0) i += (int)L * (abs(i) / L + 1);
+                    i = i % L;
+                    const int cr = code_iq[2 * i], ci = code_iq[2 * i + 1];
+                    /* lv_16sc_t tmp = tmp16 * in_a[n]: evaluated in int, stored as int16 (:110) */
+                    const int16_t mr = (int16_t)(yr * cr - yi * ci);
+                    const int16_t mi = (int16_t)(yr * ci + yi * cr);
+                    accr[t] = sat_adds16(accr[t], mr); /* (:112) */
+                    acci[t] = sat_adds16(acci[t], mi);
+                    exr[t] += mr;
+                    exi[t] += mi;
+                }
+        }
+    for (int t = 0; t < n_taps; t++)
+        {
+            corr_out[2 * t] = accr[t];
+            corr_out[2 * t + 1] = acci[t];
+            if (exact_sums)
+                {
+                    exact_sums[2 * t] = exr[t];
+                    exact_sums[2 * t + 1] = exi[t];
+                }
+        }
+}
+
 /* timing helper for bench.py's multi-thread CPU baseline: n_iter back-to-back calls without
  * returning to the interpreter (each call rewrites corr_out, so nothing is hoisted) */
 void orc_multicorrelator_repeat(int n_iter, float* corr_out, const float* sig_in, const float* code,

@@ -73,6 +73,14 @@ void orc_multicorrelator(float* corr_out, const float* sig_in, const float* code
     float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
     uint32_t N, int high_dyn, float* scratch);
 
+/* Cpu_Multicorrelator_16sc::Carrier_wipeoff_multicorrelator_resampler (cpu_multicorrelator_16sc.cc:78-103):
+ * lv_16sc_t input, chips and output ((re, im) int16 interleaved), saturating int16 accumulation in sample
+ * order.  n_taps <= 16.  exact_sums (optional): 2*n_taps unsaturated 32-bit sums of the same products. */
+void orc_multicorrelator_16sc(int16_t* corr_out, const int16_t* sig_in, const int16_t* code_iq,
+    uint32_t code_length_chips, const float* shifts_chips, int n_taps,
+    float rem_carrier_phase_rad, float phase_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, uint32_t N, int32_t* exact_sums);
+
 /* n_iter back-to-back orc_multicorrelator calls (timing helper of bench.py's threaded CPU baseline) */
 void orc_multicorrelator_repeat(int n_iter, float* corr_out, const float* sig_in, const float* code,
     uint32_t code_length_chips, const float* shifts_chips, int n_taps,

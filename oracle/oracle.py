@@ -87,6 +87,7 @@ class Oracle:
         L.orc_resampler_high_dyn.argtypes = [c_int32_p, c_float_p, c_float_p, C.c_float, C.c_float, C.c_float, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_rotator_dot_prod.argtypes = [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_multicorrelator.argtypes = [c_float_p, c_float_p, c_float_p, C.c_uint32, c_float_p, C.c_int] + [C.c_float] * 6 + [C.c_uint32, C.c_int, c_float_p]
+        L.orc_multicorrelator_16sc.argtypes = [C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.c_uint32, c_float_p, C.c_int] + [C.c_float] * 4 + [C.c_uint32, c_int32_p]
         L.orc_multicorrelator_repeat.argtypes = [C.c_int] + L.orc_multicorrelator.argtypes
         L.orc_resampler_cc.argtypes = [c_float_p, c_float_p, C.c_float, C.c_float, c_float_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_multicorrelator_cc.argtypes = [c_float_p, c_float_p, c_float_p, C.c_uint32, c_float_p, C.c_int] + [C.c_float] * 4 + [C.c_uint32, c_float_p]
@@ -134,6 +135,20 @@ class Oracle:
             _fp(code), len(code), _fp(shifts), len(shifts), rem_carr, phase_step, phase_rate_step,
             rem_code, code_step, code_rate_step, N, int(high_dyn), _fp(scratch))
         return out
+
+    def multicorrelator_16sc(self, sig, code, shifts, rem_carr, phase_step, rem_code, code_step, N):
+        """Cpu_Multicorrelator_16sc::Carrier_wipeoff_multicorrelator_resampler.  sig, code: int16 arrays of
+        shape (n, 2).  Returns (saturating int16 result (n_taps, 2), unsaturated int32 sums (n_taps, 2))."""
+        sig = np.ascontiguousarray(sig, np.int16)
+        code = np.ascontiguousarray(code, np.int16)
+        shifts = np.ascontiguousarray(shifts, np.float32)
+        assert sig.shape[0] >= N and sig.shape[1] == 2 and code.shape[1] == 2
+        out = np.zeros((len(shifts), 2), np.int16)
+        exact = np.zeros((len(shifts), 2), np.int32)
+        p16 = C.POINTER(C.c_int16)
+        self.lib.orc_multicorrelator_16sc(out.ctypes.data_as(p16), sig.ctypes.data_as(p16), code.ctypes.data_as(p16), code.shape[0],
+            _fp(shifts), len(shifts), rem_carr, phase_step, rem_code, code_step, N, exact.ctypes.data_as(c_int32_p))
+        return out, exact
 
     def multicorrelator_repeat(self, n_iter, sig, code, shifts, rem_carr, phase_step, rem_code, code_step, N):
         """n_iter back-to-back multicorrelator calls inside C (GIL released): timing only."""
@@ -284,6 +299,7 @@ class Ref:
         L.ref_resampler_u_avx.argtypes = L.ref_resampler_generic.argtypes
         L.ref_resampler_high_dyn_generic.argtypes = [pp, c_float_p, C.c_float, C.c_float, C.c_float, c_float_p, C.c_uint, C.c_int, C.c_uint]
         L.ref_resampler_cc_generic.argtypes = L.ref_resampler_generic.argtypes
+        L.ref_resampler_16ic_generic.argtypes = [C.POINTER(C.POINTER(C.c_int16)), C.POINTER(C.c_int16), C.c_float, C.c_float, c_float_p, C.c_uint, C.c_int, C.c_uint]
         L.ref_sincos_generic.argtypes = [c_float_p, C.c_float, c_float_p, C.c_uint]
         L.ref_index_max_generic.argtypes = [c_float_p, C.c_uint]
         L.ref_index_max_generic.restype = C.c_uint
@@ -317,6 +333,17 @@ class Ref:
         res = np.zeros((nt, N + 16), np.complex64)
         rows = (c_float_p * nt)(*[res[t].view(np.float32).ctypes.data_as(c_float_p) for t in range(nt)])
         self.lib.ref_resampler_cc_generic(rows, code.view(np.float32).ctypes.data_as(c_float_p), rem, step, _fp(shifts), len(code), nt, N)
+        return res[:, :N].copy()
+
+    def resampler_16ic(self, code, rem, step, shifts, N):
+        """volk_gnsssdr_16ic_xn_resampler_16ic_xn_generic of the reference: (n_taps, N, 2) int16."""
+        code = np.ascontiguousarray(code, np.int16)
+        shifts = np.ascontiguousarray(shifts, np.float32).copy()
+        nt = len(shifts)
+        res = np.zeros((nt, N + 16, 2), np.int16)
+        p16 = C.POINTER(C.c_int16)
+        rows = (p16 * nt)(*[res[t].ctypes.data_as(p16) for t in range(nt)])
+        self.lib.ref_resampler_16ic_generic(rows, code.ctypes.data_as(p16), rem, step, _fp(shifts), code.shape[0], nt, N)
         return res[:, :N].copy()
 
     def sincos(self, phase_inc, N, phase0=0.0):

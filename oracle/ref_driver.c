@@ -7,7 +7,7 @@
  * (-I paths only, nothing copied) and exports plain symbols that forward to
  * them.  Only kernels whose headers need nothing generated are included:
  *   volk_gnsssdr_32f_xn_resampler_32f_xn.h, …_high_dynamics_resampler_…,
- *   volk_gnsssdr_32fc_xn_resampler_32fc_xn.h,
+ *   volk_gnsssdr_32fc_xn_resampler_32fc_xn.h, volk_gnsssdr_16ic_xn_resampler_16ic_xn.h,
  *   volk_gnsssdr_s32f_sincos_32fc.h, volk_gnsssdr_32f_index_max_32u.h.
  * The rotator/dot-product headers include the Mako-generated
  * <volk_gnsssdr/volk_gnsssdr.h>, which does not exist in this image, so they
@@ -26,6 +26,7 @@
 #include "volk_gnsssdr_32f_xn_resampler_32f_xn.h"
 #include "volk_gnsssdr_32f_xn_high_dynamics_resampler_32f_xn.h"
 #include "volk_gnsssdr_32fc_xn_resampler_32fc_xn.h"
+#include "volk_gnsssdr_16ic_xn_resampler_16ic_xn.h"
 #include "volk_gnsssdr_s32f_sincos_32fc.h"
 #include "volk_gnsssdr_32f_index_max_32u.h"
 
@@ -51,6 +52,14 @@ void ref_resampler_cc_generic(float** result /* interleaved complex rows */, con
     int num_out_vectors, unsigned int num_points)
 {
     volk_gnsssdr_32fc_xn_resampler_32fc_xn_generic((lv_32fc_t**)result, (const lv_32fc_t*)local_code_iq, rem_code_phase_chips,
+        code_phase_step_chips, shifts_chips, code_length_chips, num_out_vectors, num_points);
+}
+
+void ref_resampler_16ic_generic(short** result /* interleaved (re, im) int16 rows */, const short* local_code_iq,
+    float rem_code_phase_chips, float code_phase_step_chips, float* shifts_chips, unsigned int code_length_chips,
+    int num_out_vectors, unsigned int num_points)
+{
+    volk_gnsssdr_16ic_xn_resampler_16ic_xn_generic((lv_16sc_t**)result, (const lv_16sc_t*)local_code_iq, rem_code_phase_chips,
         code_phase_step_chips, shifts_chips, code_length_chips, num_out_vectors, num_points);
 }
 

@@ -74,7 +74,8 @@ def main():
     out = {}
     # ---- resampler chip indices from the compiled reference kernels ----
     cases = resampler_cases()
-    store = {"n_cases": np.int32(len(cases)), "complex_chip_resampler_checked": np.int32(1)}
+    store = {"n_cases": np.int32(len(cases)), "complex_chip_resampler_checked": np.int32(1),
+        "int16_chip_resampler_checked": np.int32(1)}
     for i, c in enumerate(cases):
         ramp = np.arange(c["L"], dtype=np.float32)
         idx = ref.resampler(ramp, c["rem"], c["step"], c["shifts"], c["N"]).astype(np.int16)
@@ -92,6 +93,10 @@ def main():
         rcc = ref.resampler_cc(cramp, c["rem"], c["step"], c["shifts"], c["N"])
         assert (rcc.real.astype(np.int16) == idx).all() and (rcc.imag.astype(np.int16) == c["L"] - idx).all()
         assert (orc.resampler_cc(cramp, c["rem"], c["step"], c["shifts"], c["N"]) == rcc).all()
+        # ... and so does the 16-bit one (Cpu_Multicorrelator_16sc)
+        iramp = np.stack([np.arange(c["L"]), c["L"] - np.arange(c["L"])], 1).astype(np.int16)
+        r16 = ref.resampler_16ic(iramp, c["rem"], c["step"], c["shifts"], c["N"])
+        assert (r16[:, :, 0] == idx).all() and (r16[:, :, 1] == c["L"] - idx).all()
         # the oracle restatement must agree bit for bit before anything is written
         assert (orc.resampler_indices(c["rem"], c["step"], c["shifts"], c["L"], c["N"]) == idx).all()
         if c["N"] >= 16:

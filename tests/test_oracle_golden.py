@@ -32,7 +32,7 @@ def test_complex_chip_resampler_walks_the_same_indices(oracle):
     """make_golden.py asserted that the reference's volk_gnsssdr_32fc_xn_resampler_32fc_xn_generic
     (Cpu_Multicorrelator) gathers exactly the indices stored for the real-code resampler."""
     z = np.load(os.path.join(G, "ref_resampler.npz"))
-    assert int(z["complex_chip_resampler_checked"]) == 1
+    assert int(z["complex_chip_resampler_checked"]) == 1 and int(z["int16_chip_resampler_checked"]) == 1
     for i in range(int(z["n_cases"])):
         L, N = (int(v) for v in z["c%d_params" % i])
         rem, step, _ = (np.float32(v) for v in z["c%d_f" % i])

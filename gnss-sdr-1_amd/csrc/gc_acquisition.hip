@@ -5,6 +5,7 @@
 // same input block.
 #include "acq_kernels.h"
 #include "gc_internal.h"
+#include "gc_stream.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 struct gc_acq
 {
     gc_ctx* ctx = nullptr;
+    gc_ctx_ref ctx_ref;
     gc_acq_conf conf{};
     int n_sats = 0;
     uint32_t fft_size = 0, consumed = 0, eff = 0, n_bins = 0;  // n_bins: bins of the ACTIVE grid
@@ -94,6 +96,7 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     gc_device_guard g(ctx->device);
     gc_acq* a = new gc_acq();
     a->ctx = ctx;
+    a->ctx_ref.bind(ctx);
     a->conf = *conf;
     a->n_sats = n_sats;
     // pcps_acquisition.cc:77-85, :113-117
@@ -430,6 +433,30 @@ gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_resu
     GC_HIP(hipMemcpyAsync(a->d_in, host_iq, sizeof(float2) * a->consumed, hipMemcpyHostToDevice, st));
     gc_status s = acq_enqueue(a, a->d_in, GC_IQ_F32, st);
     if (s != GC_OK) return s;
+    return acq_fetch(a, host_results, st);
+}
+
+gc_status gc_acq_dwell_stream(gc_acq* a, gc_stream* s, uint64_t first_index, gc_acq_result* host_results)
+{
+    GC_REQUIRE(a && s && host_results, "gc_acq_dwell_stream: NULL argument");
+    GC_REQUIRE(s->ctx->device == a->ctx->device, "gc_acq_dwell_stream: the stream lives on another GPU");
+    GC_REQUIRE(s->iq_format == a->iq_format, "gc_acq_dwell_stream: stream format %d, acquisition format %d (gc_acq_set_input_format)",
+        s->iq_format, a->iq_format);
+    GC_REQUIRE(a->consumed <= s->mirror, "gc_acq_dwell_stream: the block of %u samples is longer than the stream's max_window", a->consumed);
+    uint64_t oldest = 0, head = 0;
+    gc_stream_info(s, &oldest, &head, nullptr);
+    GC_REQUIRE(first_index >= oldest && first_index + a->consumed <= head,
+        "gc_acq_dwell_stream: block [%llu, +%u) is not inside the stream's resident samples [%llu, %llu)",
+        (unsigned long long)first_index, a->consumed, (unsigned long long)oldest, (unsigned long long)head);
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = a->ctx->stream;
+    gc_status rs = gc_stream_begin_read(s, st);
+    if (rs != GC_OK) return rs;
+    rs = acq_enqueue(a, s->d_ring + (first_index % s->capacity) * s->elem, a->iq_format, st);
+    if (rs != GC_OK) return rs;
+    rs = gc_stream_end_read(s, st, first_index);
+    if (rs != GC_OK) return rs;
     return acq_fetch(a, host_results, st);
 }
 

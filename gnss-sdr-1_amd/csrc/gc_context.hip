@@ -21,6 +21,20 @@ gc_status gc_fail(gc_status st, const char* fmt, ...)
     return st;
 }
 
+void gc_ctx_retain(gc_ctx* ctx) { ctx->refs.fetch_add(1); }
+
+void gc_ctx_release(gc_ctx* ctx)
+{
+    if (ctx->refs.fetch_sub(1) != 1) return;
+    gc_device_guard g(ctx->device);
+    if (ctx->stream)
+        {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamDestroy(ctx->stream);
+        }
+    delete ctx;
+}
+
 extern "C" {
 
 const char* gc_last_error(void) { return g_err; }
@@ -64,13 +78,7 @@ gc_status gc_ctx_create(int device, gc_ctx** out)
 gc_status gc_ctx_destroy(gc_ctx* ctx)
 {
     if (!ctx) return GC_OK;
-    gc_device_guard g(ctx->device);
-    if (ctx->stream)
-        {
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipStreamDestroy(ctx->stream);
-        }
-    delete ctx;
+    gc_ctx_release(ctx);  // the context lives on while handles created on it exist
     return GC_OK;
 }
 

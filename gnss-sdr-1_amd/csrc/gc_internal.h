@@ -5,6 +5,7 @@
 #include "gnsscorr.h"
 #include <hip/hip_runtime.h>
 #include <cstdarg>
+#include <atomic>
 #include <cstdio>
 #include <mutex>
 
@@ -36,6 +37,27 @@ struct gc_ctx
     int n_cus = 0;
     size_t lds_max = 0;
     std::mutex mtx;  // serialises entry points that share this context's scratch
+    // one reference for the creator (dropped by gc_ctx_destroy) + one per live handle created on the context:
+    // the stream and the struct go away with the last of them, so handles may be destroyed in any order
+    std::atomic<int> refs{1};
+};
+
+void gc_ctx_retain(gc_ctx* ctx);
+void gc_ctx_release(gc_ctx* ctx);
+
+// member of every handle struct: keeps the context alive for the handle's lifetime
+struct gc_ctx_ref
+{
+    gc_ctx* p = nullptr;
+    void bind(gc_ctx* c)
+    {
+        p = c;
+        gc_ctx_retain(c);
+    }
+    ~gc_ctx_ref()
+    {
+        if (p) gc_ctx_release(p);
+    }
 };
 
 // RAII device selection for entry points (contexts may live on different GPUs)

@@ -6,7 +6,9 @@
 //                        and, with complex chips, of Cpu_Multicorrelator
 //                        (src/algorithms/tracking/libs/cpu_multicorrelator.h:46-64)
 #include "gc_internal.h"
+#include "gc_stream.h"
 #include "trk_kernels.h"
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -43,6 +45,7 @@ extern "C" void gc_epoch_params_fill(gc_epoch_params* p, uint64_t sample_offset,
 struct gc_trk_batch
 {
     gc_ctx* ctx = nullptr;
+    gc_ctx_ref ctx_ref;
     int n_channels = 0, n_taps = 0, max_code_len = 0, mode = TRK_MODE_PLAIN;
     int lds_table_floats = 0;
     int nominal_len = 0;
@@ -50,6 +53,9 @@ struct gc_trk_batch
     int forced_slices = 0;
     bool complex_codes = false;
     bool sc16 = false;  // Cpu_Multicorrelator_16sc arithmetic: int16 IQ, int16 complex chips, int16 results
+    std::vector<gc_stream*> streams;  // per channel: the ring it reads (gc_trk_batch_set_input_stream) or NULL
+    bool has_read_floor = false;
+    uint64_t read_floor = 0;  // oldest absolute index run_dev launches may read (gc_trk_batch_set_read_floor)
     std::vector<TrkChan> h_chans;
     bool chans_dirty = true;
     TrkChan* d_chans = nullptr;
@@ -104,12 +110,14 @@ gc_status gc_trk_batch_create(gc_ctx* ctx, int n_channels, int n_taps, int max_c
     gc_device_guard g(ctx->device);
     gc_trk_batch* b = new gc_trk_batch();
     b->ctx = ctx;
+    b->ctx_ref.bind(ctx);
     b->n_channels = n_channels;
     b->n_taps = n_taps;
     b->max_code_len = max_code_length;
     b->mode = high_dyn ? TRK_MODE_HD_FULL : TRK_MODE_PLAIN;
     b->lds_table_floats = max_code_length + 64;
     b->h_chans.assign(n_channels, TrkChan{});
+    b->streams.assign(n_channels, nullptr);
     hipError_t e1 = hipMalloc(&b->d_chans, sizeof(TrkChan) * n_channels);
     hipError_t e2 = hipMalloc(&b->d_codes, sizeof(float) * (size_t)n_channels * max_code_length);
     if (e1 != hipSuccess || e2 != hipSuccess)
@@ -139,6 +147,8 @@ gc_status gc_trk_batch_destroy(gc_trk_batch* b)
     (void)hipFree(b->d_partial);
     (void)hipFree(b->d_params);
     (void)hipFree(b->d_out);
+    for (gc_stream* r : b->streams)
+        if (r) gc_stream_drop(r);
     delete b;
     return GC_OK;
 }
@@ -248,7 +258,34 @@ gc_status gc_trk_batch_set_input_dev(gc_trk_batch* b, int ch, const void* dev_iq
     GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) % es) == 0, "gc_trk_batch_set_input_dev: IQ pointer must be aligned to one sample (%d bytes)", (int)es);
     b->h_chans[ch].iq = dev_iq;
     b->h_chans[ch].n_iq = n_samples;
+    b->h_chans[ch].ring_len = 0;
+    if (b->streams[ch]) gc_stream_drop(b->streams[ch]);
+    b->streams[ch] = nullptr;
     b->chans_dirty = true;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_input_stream(gc_trk_batch* b, int ch, gc_stream* s)
+{
+    GC_REQUIRE(b && s, "gc_trk_batch_set_input_stream: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < b->n_channels, "gc_trk_batch_set_input_stream: channel %d out of range", ch);
+    GC_REQUIRE(s->ctx->device == b->ctx->device, "gc_trk_batch_set_input_stream: the stream lives on another GPU");
+    GC_REQUIRE(s->iq_format == b->iq_format, "gc_trk_batch_set_input_stream: stream format %d, batch format %d", s->iq_format, b->iq_format);
+    gc_stream_keep(s);
+    if (b->streams[ch]) gc_stream_drop(b->streams[ch]);
+    b->h_chans[ch].iq = s->d_ring;
+    b->h_chans[ch].n_iq = ~0ull;
+    b->h_chans[ch].ring_len = (unsigned)s->capacity;
+    b->streams[ch] = s;
+    b->chans_dirty = true;
+    return GC_OK;
+}
+
+gc_status gc_trk_batch_set_read_floor(gc_trk_batch* b, uint64_t oldest_index_read)
+{
+    GC_REQUIRE(b, "gc_trk_batch_set_read_floor: NULL argument");
+    b->has_read_floor = true;
+    b->read_floor = oldest_index_read;
     return GC_OK;
 }
 
@@ -264,6 +301,12 @@ gc_status gc_trk_batch_set_input_format(gc_trk_batch* b, int iq_format)
                 {
                     c.iq = nullptr;
                     c.n_iq = 0;
+                    c.ring_len = 0;
+                }
+            for (gc_stream*& r : b->streams)
+                {
+                    if (r) gc_stream_drop(r);
+                    r = nullptr;
                 }
             b->chans_dirty = true;
         }
@@ -286,8 +329,18 @@ gc_status gc_trk_batch_set_slices(gc_trk_batch* b, int n_slices)
     return GC_OK;
 }
 
+// distinct rings the batch reads
+static std::vector<gc_stream*> batch_streams(const gc_trk_batch* b)
+{
+    std::vector<gc_stream*> v;
+    for (gc_stream* s : b->streams)
+        if (s && std::find(v.begin(), v.end(), s) == v.end()) v.push_back(s);
+    return v;
+}
+
+// floors: oldest absolute index the launch reads from each ring of batch_streams(b) (NULL: unknown)
 static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_params* dev_params, void* dev_out,
-    hipStream_t st, int max_len)
+    hipStream_t st, int max_len, const std::vector<uint64_t>* floors = nullptr)
 {
     for (int i = 0; i < b->n_channels; i++)
         {
@@ -310,9 +363,22 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
                     b->partial_cap = need;
                 }
         }
+    const std::vector<gc_stream*> rings = batch_streams(b);
+    for (gc_stream* r : rings)
+        {
+            gc_status rs = gc_stream_begin_read(r, st);  // the newest push must have landed
+            if (rs != GC_OK) return rs;
+        }
     hipError_t e = trk_launch(b->n_taps, b->mode, b->iq_format, st, b->d_chans, dev_params, static_cast<float2*>(dev_out), b->d_partial,
         b->n_channels, n_epochs, n_slices, b->lds_table_floats);
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
+    for (size_t i = 0; i < rings.size(); i++)
+        {
+            // later pushes may evict everything below the floor while this launch is still running
+            const uint64_t floor = floors ? (*floors)[i] : b->has_read_floor ? b->read_floor : gc_stream_oldest(rings[i]);
+            gc_status rs = gc_stream_end_read(rings[i], st, floor);
+            if (rs != GC_OK) return rs;
+        }
     return GC_OK;
 }
 
@@ -333,14 +399,31 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
     std::lock_guard<std::mutex> lk(b->ctx->mtx);
     const size_t jobs = (size_t)b->n_channels * n_epochs;
     int max_len = 0;
+    const std::vector<gc_stream*> rings = batch_streams(b);
+    std::vector<uint64_t> floors(rings.size(), ~0ull);
     for (size_t j = 0; j < jobs; j++)
         {
             const gc_epoch_params& p = host_params[j];
             const TrkChan& c = b->h_chans[j / n_epochs];
             GC_REQUIRE(p.n_samples >= 0, "gc_trk_batch_run: job %zu has negative n_samples", j);
-            GC_REQUIRE(p.sample_offset + (uint64_t)p.n_samples <= c.n_iq,
-                "gc_trk_batch_run: job %zu window [%llu, +%d) exceeds the channel's %llu samples", j,
-                (unsigned long long)p.sample_offset, p.n_samples, (unsigned long long)c.n_iq);
+            if (gc_stream* r = b->streams[j / n_epochs])
+                {
+                    uint64_t oldest = 0, head = 0;
+                    gc_stream_info(r, &oldest, &head, nullptr);
+                    GC_REQUIRE((uint64_t)p.n_samples <= r->mirror, "gc_trk_batch_run: job %zu is longer than the stream's max_window %llu", j,
+                        (unsigned long long)r->mirror);
+                    GC_REQUIRE(p.sample_offset >= oldest && p.sample_offset + (uint64_t)p.n_samples <= head,
+                        "gc_trk_batch_run: job %zu window [%llu, +%d) is not inside the stream's resident samples [%llu, %llu)", j,
+                        (unsigned long long)p.sample_offset, p.n_samples, (unsigned long long)oldest, (unsigned long long)head);
+                    const size_t ri = std::find(rings.begin(), rings.end(), r) - rings.begin();
+                    floors[ri] = std::min(floors[ri], p.sample_offset);
+                }
+            else
+                {
+                    GC_REQUIRE(p.sample_offset + (uint64_t)p.n_samples <= c.n_iq,
+                        "gc_trk_batch_run: job %zu window [%llu, +%d) exceeds the channel's %llu samples", j,
+                        (unsigned long long)p.sample_offset, p.n_samples, (unsigned long long)c.n_iq);
+                }
             if (p.n_samples > max_len) max_len = p.n_samples;
         }
     hipStream_t st = b->ctx->stream;
@@ -361,7 +444,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
             b->out_cap = jobs * b->n_taps;
         }
     GC_HIP(hipMemcpyAsync(b->d_params, host_params, jobs * sizeof(gc_epoch_params), hipMemcpyHostToDevice, st));
-    gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len);
+    gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len, &floors);
     if (s != GC_OK) return s;
     // 16-bit mode: n_taps lv_16sc_t (4 bytes) per job instead of n_taps complex floats
     const size_t out_elem = b->sc16 ? sizeof(short2) : sizeof(float2);
@@ -378,6 +461,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
 struct gc_correlator
 {
     gc_ctx* ctx = nullptr;
+    gc_ctx_ref ctx_ref;
     bool use_high_dynamics_resampler = true;  // reference ctor default (cpu_multicorrelator_real_codes.cc:49)
     bool inited = false;
     int max_len = 0, n_corr = 0;
@@ -510,6 +594,7 @@ gc_status gc_correlator_create(gc_ctx* ctx, gc_correlator** out)
     GC_REQUIRE(ctx && out, "gc_correlator_create: NULL argument");
     gc_correlator* c = new gc_correlator();
     c->ctx = ctx;
+    c->ctx_ref.bind(ctx);
     *out = c;
     return GC_OK;
 }

@@ -447,6 +447,7 @@ __global__ void trk_loop_start_kernel(LoopChan* chans, int ch)
 struct gc_trk_loop
 {
     gc_ctx* ctx = nullptr;
+    gc_ctx_ref ctx_ref;
     int n_channels = 0, max_code_len = 0, n_taps = 0;
     LoopChan* d_chans = nullptr;
     float* d_codes = nullptr;
@@ -468,6 +469,7 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
     gc_device_guard g(ctx->device);
     gc_trk_loop* l = new gc_trk_loop();
     l->ctx = ctx;
+    l->ctx_ref.bind(ctx);
     l->n_channels = n_channels;
     l->max_code_len = max_code_length;
     hipError_t e1 = hipMalloc(&l->d_chans, sizeof(LoopChan) * n_channels);

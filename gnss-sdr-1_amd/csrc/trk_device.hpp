@@ -405,7 +405,7 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
     const int L = cd.code_len;
 
     typedef typename IqFmt<FMT>::elem elem_t;
-    const elem_t* iq = static_cast<const elem_t*>(cd.iq) + p.sample_offset;
+    const elem_t* iq = static_cast<const elem_t*>(cd.iq) + (cd.ring_len ? p.sample_offset % cd.ring_len : p.sample_offset);
     const int a = (int)((reinterpret_cast<uintptr_t>(iq) / sizeof(elem_t)) & 1);  // 1: window starts on the odd half of a sample pair
     // pair-aligned; sample n lives at base[n + a].  IQ lives in HBM: global (not flat) loads
     const GC_GLOBAL elem_t* base = (const GC_GLOBAL elem_t*)(iq - a);

@@ -13,7 +13,8 @@ struct TrkChan
     unsigned long long n_iq;   // samples available at iq
     const float* code;         // code table (HBM): code_len floats, or code_len (re, im) pairs in TRK_MODE_COMPLEX_CODE
     int code_len;
-    int reserved;
+    unsigned ring_len;         // 0: sample_offset is relative to iq; else iq is a gc_stream ring of ring_len samples and
+                               // sample_offset an absolute sample number (the window is contiguous thanks to the mirror)
     float shifts[GC_MAX_TAPS]; // tap shifts in code samples
 };
 

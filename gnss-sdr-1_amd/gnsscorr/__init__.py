@@ -142,6 +142,14 @@ API = {
     "gc_correlator_set_local_code_and_taps_16sc": (C.c_int, [_vp, C.c_int, _i16p, _fp]),
     "gc_correlator_set_input_output_vectors_16sc": (C.c_int, [_vp, _i16p, _i16p]),
     "gc_epoch_params_fill": (None, [C.POINTER(EpochParams), C.c_uint64] + [C.c_float] * 6 + [C.c_int]),
+    "gc_stream_create": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
+    "gc_stream_destroy": (C.c_int, [_vp]),
+    "gc_stream_push": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "gc_stream_info": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gc_stream_synchronize": (C.c_int, [_vp]),
+    "gc_trk_batch_set_input_stream": (C.c_int, [_vp, C.c_int, _vp]),
+    "gc_trk_batch_set_read_floor": (C.c_int, [_vp, C.c_uint64]),
+    "gc_acq_dwell_stream": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "gc_trk_batch_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gc_trk_batch_destroy": (C.c_int, [_vp]),
     "gc_trk_batch_set_code": (C.c_int, [_vp, C.c_int, _fp, C.c_int, _fp]),
@@ -302,6 +310,46 @@ class Context:
     def close(self):
         if self._h:
             load_library().gc_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class IqStream:
+    """HBM ring of one RF stream (gc_stream_*): push host blocks once, every channel / acquisition of the
+    stream reads them by absolute sample number."""
+    _DTYPES = {GC_IQ_F32: (np.complex64, 1), GC_IQ_I16: (np.int16, 2), GC_IQ_I8: (np.int8, 2)}
+
+    def __init__(self, ctx, capacity_samples, max_window_samples, iq_format=GC_IQ_F32):
+        self._ctx = ctx
+        self.iq_format = iq_format
+        self._h = _vp()
+        _check(load_library().gc_stream_create(ctx._h, int(iq_format), int(capacity_samples), int(max_window_samples), C.byref(self._h)))
+
+    def push(self, block):
+        """block: complex64 [n] (GC_IQ_F32) or int16 / int8 [n, 2].  Returns the absolute index of its first sample."""
+        dt, per = self._DTYPES[self.iq_format]
+        block = np.ascontiguousarray(block, dt)
+        n = block.size // per
+        first = C.c_uint64(0)
+        _check(load_library().gc_stream_push(self._h, block.ctypes.data_as(_vp), n, C.byref(first)))
+        return int(first.value)
+
+    def info(self):
+        o, h, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().gc_stream_info(self._h, C.byref(o), C.byref(h), C.byref(c)))
+        return int(o.value), int(h.value), int(c.value)
+
+    def synchronize(self):
+        _check(load_library().gc_stream_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            load_library().gc_stream_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):
@@ -476,6 +524,14 @@ class TrackingBatch:
     def set_input_dev(self, ch, dev_ptr, n_samples):
         _check(load_library().gc_trk_batch_set_input_dev(self._h, ch, _vp(dev_ptr), int(n_samples)))
 
+    def set_input_stream(self, ch, stream):
+        _check(load_library().gc_trk_batch_set_input_stream(self._h, ch, stream._h))
+        self._streams = getattr(self, "_streams", {})
+        self._streams[ch] = stream  # keep the ring alive
+
+    def set_read_floor(self, oldest_index_read):
+        _check(load_library().gc_trk_batch_set_read_floor(self._h, int(oldest_index_read)))
+
     def set_nominal_length(self, n):
         _check(load_library().gc_trk_batch_set_nominal_length(self._h, int(n)))
 
@@ -586,6 +642,11 @@ class PcpsAcquisition:
         assert iq.size >= self.consumed_samples
         res = (AcqResult * self.n_sats)()
         _check(load_library().gc_acq_dwell(self._h, iq.view(np.float32).ctypes.data_as(_fp), res))
+        return list(res)
+
+    def dwell_stream(self, stream, first_index):
+        res = (AcqResult * self.n_sats)()
+        _check(load_library().gc_acq_dwell_stream(self._h, stream._h, int(first_index), C.cast(res, _vp)))
         return list(res)
 
     def set_input_format(self, iq_format):

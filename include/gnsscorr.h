@@ -63,6 +63,9 @@ int gc_device_count(void);
 /* ------------------------------------------------------------------------ */
 typedef struct gc_ctx gc_ctx;
 gc_status gc_ctx_create(int device, gc_ctx** out);
+/* Drops the caller's reference.  Handles created on the context keep it (and its
+ * stream) alive until the last of them is destroyed, so the order of the destroy
+ * calls does not matter; the same holds for a gc_stream and the batches reading it. */
 gc_status gc_ctx_destroy(gc_ctx* ctx);
 gc_status gc_ctx_synchronize(gc_ctx* ctx);
 
@@ -131,6 +134,28 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlato
 gc_status gc_correlator_set_local_code_and_taps_16sc(gc_correlator* c, int code_length_chips,
     const int16_t* local_code_in_iq, float* shifts_chips);
 gc_status gc_correlator_set_input_output_vectors_16sc(gc_correlator* c, int16_t* corr_out, const int16_t* sig_in);
+
+/* ------------------------------------------------------------------------ */
+/* RF stream ring: the IQ samples of one RF stream, pushed to a GPU once and    */
+/* read by every channel / acquisition of that stream (all channels of a        */
+/* GNSS-SDR flowgraph read the same stream, gnss_flowgraph.cc:496-499).  A ring  */
+/* of capacity_samples in HBM plus a mirror of its first max_window_samples, so  */
+/* that any window of <= max_window_samples is contiguous; consumers address it  */
+/* with ABSOLUTE sample numbers (0 = first sample ever pushed).  Pushes are      */
+/* asynchronous (own HIP stream, pinned staging) and overlap with compute; a     */
+/* push waits only for launches that may still read the samples it evicts.       */
+/* ------------------------------------------------------------------------ */
+typedef struct gc_stream gc_stream;
+gc_status gc_stream_create(gc_ctx* ctx, int iq_format, uint64_t capacity_samples, uint32_t max_window_samples,
+    gc_stream** out);
+gc_status gc_stream_destroy(gc_stream* s);
+/* Appends n_samples (host memory, gc_iq_format of the stream; at most capacity_samples per call).
+ * first_index (optional) receives the absolute number of the first appended sample. */
+gc_status gc_stream_push(gc_stream* s, const void* host_iq, uint64_t n_samples, uint64_t* first_index);
+/* Resident range [oldest_index, head_index) and the ring capacity (any pointer may be NULL). */
+gc_status gc_stream_info(gc_stream* s, uint64_t* oldest_index, uint64_t* head_index, uint64_t* capacity_samples);
+/* Waits until every push so far has landed in HBM. */
+gc_status gc_stream_synchronize(gc_stream* s);
 
 /* ------------------------------------------------------------------------ */
 /* Level 2 -- batched tracking engine: all channels of a GPU, many epochs,    */
@@ -202,6 +227,13 @@ gc_status gc_trk_batch_set_input_format(gc_trk_batch* b, int iq_format);
 /* Points channel `ch` at its IQ samples in HBM (n_samples complex samples of the batch's format,
  * aligned to one sample).  Channels of one RF stream may share the same pointer. */
 gc_status gc_trk_batch_set_input_dev(gc_trk_batch* b, int ch, const void* dev_iq, uint64_t n_samples);
+/* Channel `ch` reads the ring `s` (same format as the batch): gc_epoch_params.sample_offset is then an
+ * ABSOLUTE sample number of that stream and n_samples <= the stream's max_window.  gc_trk_batch_run checks
+ * every window against the resident range; gc_trk_batch_run_dev cannot (parameters live in HBM): tell it the
+ * oldest sample its launches read with set_read_floor so that later pushes need not wait for them (default:
+ * everything resident, i.e. the next evicting push waits for the launch). */
+gc_status gc_trk_batch_set_input_stream(gc_trk_batch* b, int ch, gc_stream* s);
+gc_status gc_trk_batch_set_read_floor(gc_trk_batch* b, uint64_t oldest_index_read);
 /* Correlates n_epochs epochs of every channel.  dev_params: n_channels*n_epochs
  * gc_epoch_params, channel-major.  dev_out: n_channels*n_epochs*n_taps complex.
  * Asynchronous on `stream`. */
@@ -374,6 +406,9 @@ gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_resu
  * gc_acq_fetch_results(). */
 gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream);
 gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* stream);
+/* One dwell on the block of consumed_samples that starts at absolute sample first_index of the ring `s`
+ * (the stream's format must equal gc_acq_set_input_format's; synchronous like gc_acq_dwell). */
+gc_status gc_acq_dwell_stream(gc_acq* a, gc_stream* s, uint64_t first_index, gc_acq_result* host_results);
 /* Copies satellite `sat`'s magnitude grid (num_doppler_bins * fft_size floats) to host. */
 gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid);
 

@@ -26,12 +26,15 @@ def test_cpp_adapter_selftest():
         assert "adapter self-test passed" in p.stdout
         # acquisition dump: the variables of pcps_acquisition::dump_results (pcps_acquisition.cc:462-562) under the
         # reference's file name <dump_filename>_<System>_<Signal>_ch_<channel>_<n>_sat_<PRN>.mat
-        m = scipy.io.loadmat(os.path.join(d, "acq_dump_G_1C_ch_1_1_sat_1.mat"), squeeze_me=True)
+        first = os.path.join(d, "acq_dump_G_1C_ch_1_1_sat_1.mat")
+        classes = {name: (shape, cls) for name, shape, cls in scipy.io.whosmat(first)}
+        assert classes["acq_grid"] == ((4000, 100), "single")  # effective_fft_size x num_doppler_bins
+        assert classes["doppler_max"] == ((1, 1), "uint32") and classes["d_positive_acq"] == ((1, 1), "int32")
+        assert classes["sample_counter"] == ((1, 1), "uint64") and classes["test_statistic"] == ((1, 1), "single")
+        m = scipy.io.loadmat(first, squeeze_me=True)
         grid = m["acq_grid"]
-        assert grid.dtype == np.float32 and grid.shape == (4000, 100)  # effective_fft_size x num_doppler_bins
-        assert m["doppler_max"].dtype == np.uint32 and int(m["doppler_max"]) == 5000 and int(m["doppler_step"]) == 100
-        assert m["d_positive_acq"].dtype == np.int32 and int(m["d_positive_acq"]) == 1
-        assert int(m["PRN"]) == 1 and int(m["num_dwells"]) == 1 and m["sample_counter"].dtype == np.uint64
+        assert int(m["doppler_max"]) == 5000 and int(m["doppler_step"]) == 100 and int(m["d_positive_acq"]) == 1
+        assert int(m["PRN"]) == 1 and int(m["num_dwells"]) == 1
         delay, dbin = np.unravel_index(np.argmax(grid), grid.shape)
         assert float(m["acq_delay_samples"]) == float(delay) and float(m["acq_doppler_hz"]) == -5000.0 + 100.0 * dbin
         assert abs(float(m["acq_doppler_hz"]) - 1680.0) <= 100.0

@@ -1,0 +1,145 @@
+"""GPU tests of the RF stream ring (gc_stream_*, SURVEY.md section 8b/8e "shared IQ ring per RF stream"):
+blocks pushed from the host in ragged sizes, windows addressed by absolute sample number across the ring's wrap,
+results identical to the same kernels reading one linear buffer."""
+import numpy as np
+import pytest
+
+from helpers import open_loop_params, synth_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tracking_from_ring_equals_linear_buffer(gctx, oracle):
+    import gnsscorr
+    import torch
+    fs, n, n_epochs = 4_000_000, 4000, 12
+    codes = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in (2, 5)]
+    sig, truth = synth_stream(codes, fs, n_epochs * n, seed=31, cn0_db_hz=(45.0, 48.0))
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    recs = []
+    for ch in range(2):
+        recs.append([gnsscorr.epoch_params(p["sample_offset"], float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n)
+            for p in open_loop_params(truth[ch], fs, 1023, n, n_epochs)])
+    # linear reference run
+    d_sig = torch.from_numpy(sig.view(np.float32).copy()).cuda()
+    lin = gnsscorr.TrackingBatch(gctx, 2, 3, 1023)
+    lin.set_slices(2)
+    for ch in range(2):
+        lin.set_code(ch, codes[ch], shifts)
+        lin.set_input_dev(ch, d_sig.data_ptr(), sig.size)
+    want = lin.run(n_epochs, gnsscorr.epoch_params_array(recs))
+    lin.close()
+    # ring of 2.5 epochs' capacity: the stream wraps several times; blocks of ragged sizes
+    ring = gnsscorr.IqStream(gctx, capacity_samples=10000, max_window_samples=n)
+    b = gnsscorr.TrackingBatch(gctx, 2, 3, 1023)
+    b.set_slices(2)
+    for ch in range(2):
+        b.set_code(ch, codes[ch], shifts)
+        b.set_input_stream(ch, ring)
+    got = np.zeros_like(want)
+    pushed, done = 0, 0
+    sizes = [1777, 2500, 3999, 811, 6000, 4000, 123]
+    k = 0
+    while done < n_epochs:
+        if pushed < sig.size:
+            m = min(sizes[k % len(sizes)], sig.size - pushed)
+            k += 1
+            assert ring.push(sig[pushed:pushed + m]) == pushed
+            pushed += m
+        while done < n_epochs and (done + 1) * n <= pushed:
+            # one epoch of both channels as soon as its samples are resident
+            out = b.run(1, gnsscorr.epoch_params_array([[recs[0][done]], [recs[1][done]]]))
+            got[:, done] = out[:, 0]
+            done += 1
+    oldest, head, cap = ring.info()
+    assert (head, cap) == (sig.size, 10000) and oldest == sig.size - 10000
+    assert np.array_equal(got, want)  # same kernel, same samples: bit-identical
+    # a window that has been evicted, one beyond the head, and one longer than max_window are refused
+    for bad in (gnsscorr.epoch_params(0, 0.0, 0.0, 0.0, 0.25, n), gnsscorr.epoch_params(sig.size - 10, 0.0, 0.0, 0.0, 0.25, n),
+            gnsscorr.epoch_params(sig.size - 9000, 0.0, 0.0, 0.0, 0.25, 2 * n)):
+        with pytest.raises(gnsscorr.GnsscorrError):
+            b.run(1, gnsscorr.epoch_params_array([[bad], [bad]]))
+    b.close()
+    ring.close()
+
+
+def test_int16_ring_and_run_dev_with_read_floor(gctx, oracle):
+    """cshort ring, device-resident parameters, several pushes in flight behind the compute launches."""
+    import gnsscorr
+    import torch
+    fs, n, n_epochs = 25_000_000, 25000, 8
+    code = oracle.gps_l1_ca_code(7).astype(np.float32)
+    sig, truth = synth_stream([code], fs, n_epochs * n, seed=32, cn0_db_hz=(48.0, 48.0))
+    q = np.round(sig.view(np.float32).reshape(-1, 2) * 32.0).astype(np.int16)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    ps = open_loop_params(truth[0], fs, 1023, n, n_epochs)
+    recs = [gnsscorr.epoch_params(p["sample_offset"], float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n) for p in ps]
+    d_q = torch.from_numpy(q).cuda()
+    lin = gnsscorr.TrackingBatch(gctx, 1, 3, 1023)
+    lin.set_input_format(gnsscorr.GC_IQ_I16)
+    lin.set_code(0, code, shifts)
+    lin.set_input_dev(0, d_q.data_ptr(), q.shape[0])
+    lin.set_slices(4)  # same cut of every epoch in both runs: the partial sums are added in the same order
+    want = lin.run(n_epochs, gnsscorr.epoch_params_array(recs))[0]
+    lin.close()
+    ring = gnsscorr.IqStream(gctx, capacity_samples=4 * n, max_window_samples=n, iq_format=gnsscorr.GC_IQ_I16)
+    b = gnsscorr.TrackingBatch(gctx, 1, 3, 1023)
+    b.set_input_format(gnsscorr.GC_IQ_I16)
+    b.set_code(0, code, shifts)
+    b.set_input_stream(0, ring)
+    b.set_slices(4)
+    d_params = torch.from_numpy(gnsscorr.epoch_params_array(recs).view(np.uint8)).cuda()
+    d_out = torch.zeros(n_epochs * 3, 2, device="cuda", dtype=torch.float32)
+    stream = torch.cuda.Stream()
+    for k in range(n_epochs):
+        ring.push(q[k * n:(k + 1) * n])
+        b.set_read_floor(k * n)  # this launch reads epoch k only: later pushes may evict everything older
+        b.run_dev(1, d_params.data_ptr() + 48 * k, d_out.data_ptr() + 24 * k, stream.cuda_stream)
+    stream.synchronize()
+    got = d_out.cpu().numpy().view(np.complex64).reshape(n_epochs, 3)
+    assert np.array_equal(got, want)
+    b.close()
+    ring.close()
+
+
+def test_acquisition_from_ring(gctx, oracle):
+    import json
+    import os
+    import gnsscorr
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    k = json.load(open(os.path.join(G, "kat_expected.json")))["gps_l1_ca"]
+    x = np.fromfile(os.path.join(G, k["file"]), np.complex64)
+    fs = k["fs"]
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, fs, 1, 1, np.float32(fs) * np.float32(0.001), 4000.0, 4, k["doppler_max"], k["doppler_step"])
+    acq.set_local_code(0, oracle.gps_l1_ca_code_sampled(k["prn"], fs))
+    want = acq.dwell(x[3000:7000])[0]
+    acq.reset()
+    ring = gnsscorr.IqStream(gctx, capacity_samples=9000, max_window_samples=4000)
+    ring.push(np.zeros(7500, np.complex64))  # so that the block of interest straddles the wrap: it starts at 8000 % 9000... below
+    ring.push(x[:1500])
+    ring.push(x[1500:8000])
+    got = acq.dwell_stream(ring, 7500 + 3000)[0]  # samples x[3000:7000] live at ring positions 1500 .. 5500 after wrapping
+    assert (got.indext, got.doppler_hz, got.mag, got.test_statistics) == (want.indext, want.doppler_hz, want.mag, want.test_statistics)
+    with pytest.raises(gnsscorr.GnsscorrError):
+        acq.dwell_stream(ring, 100)  # evicted
+    acq.close()
+    ring.close()
+
+
+def test_handles_outlive_their_context_and_stream():
+    """Destroy order must not matter: the context (and a ring) stay alive while handles created on them exist."""
+    import gnsscorr
+    ctx = gnsscorr.Context(0)
+    ring = gnsscorr.IqStream(ctx, 8000, 4000)
+    b = gnsscorr.TrackingBatch(ctx, 1, 3, 1023)
+    b.set_code(0, np.ones(1023, np.float32), np.zeros(3, np.float32))
+    b.set_input_stream(0, ring)
+    ring.push(np.ones(4000, np.complex64))
+    corr = gnsscorr.HipMulticorrelatorRealCodes(ctx)
+    corr.init(100, 3)
+    ctx.close()   # creator's reference only
+    ring.close()  # the batch still reads it
+    out = b.run(1, gnsscorr.epoch_params_array([[gnsscorr.epoch_params(0, 0.0, 0.0, 0.0, 0.25575, 4000)]]))
+    assert out[0, 0, 1] == np.complex64(4000)
+    b.close()
+    corr.close()

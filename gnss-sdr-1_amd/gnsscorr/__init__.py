@@ -145,6 +145,7 @@ API = {
     "gc_stream_create": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
     "gc_stream_destroy": (C.c_int, [_vp]),
     "gc_stream_push": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "gc_stream_push_pinned": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gc_stream_info": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gc_stream_synchronize": (C.c_int, [_vp]),
     "gc_trk_batch_set_input_stream": (C.c_int, [_vp, C.c_int, _vp]),
@@ -337,6 +338,12 @@ class IqStream:
         n = block.size // per
         first = C.c_uint64(0)
         _check(load_library().gc_stream_push(self._h, block.ctypes.data_as(_vp), n, C.byref(first)))
+        return int(first.value)
+
+    def push_pinned(self, host_ptr, n_samples):
+        """host_ptr: address of page-locked host memory (e.g. a pinned torch tensor's data_ptr()); no staging copy."""
+        first = C.c_uint64(0)
+        _check(load_library().gc_stream_push_pinned(self._h, _vp(host_ptr), int(n_samples), C.byref(first)))
         return int(first.value)
 
     def info(self):

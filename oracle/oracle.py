@@ -254,6 +254,9 @@ class Pcps:
 
     def set_local_code(self, code):
         code = np.ascontiguousarray(code, np.complex64)
+        # pcps_acquisition::set_local_code reads consumed samples (fft_size / 2 with bit_transition_flag)
+        need = self.p.contents.fft_size // 2 if self.p.contents.bit_transition_flag else self.p.contents.consumed_samples
+        assert code.size >= need, "local code has %d samples, set_local_code reads %d" % (code.size, need)
         self.orc.lib.orc_pcps_set_local_code(self.p, code.view(np.float32).ctypes.data_as(c_float_p))
 
     def core(self, x):

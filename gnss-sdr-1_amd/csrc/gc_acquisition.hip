@@ -48,6 +48,7 @@ struct gc_acq
     gc_acq_result* d_results = nullptr;
     gc_acq_result* h_results = nullptr;  // pinned
     std::vector<char> code_set;
+    bool grid_logically_zero = true;  // gc_acq_reset() since the last dwell: the grid reads as zeros
 };
 
 static void acq_release(gc_acq* a)
@@ -260,9 +261,11 @@ gc_status gc_acq_reset(gc_acq* a)
     GC_REQUIRE(a, "gc_acq_reset: NULL handle");
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
-    // grid reset (:917-924) and d_num_noncoherent_integrations_counter = 0
-    GC_HIP(hipMemsetAsync(a->d_grid, 0, (size_t)a->n_sats * a->n_bins_alloc * a->fft_size * sizeof(float), a->ctx->stream));
+    // grid reset (:917-924) and d_num_noncoherent_integrations_counter = 0.  The first dwell after a reset
+    // STORES |.|^2 into every kept cell (accumulate = 0), so nothing has to be written here: a 131 MB memset per
+    // search at cfg4 sizes, and it would have to be ordered against dwells enqueued on caller streams.
     a->dwell_counter = 0;
+    a->grid_logically_zero = true;
     return GC_OK;
 }
 
@@ -375,6 +378,7 @@ static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hi
             e = acq_launch_final(st, f, a->n_sats);
         }
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: kernel launch failed: %s", hipGetErrorString(e));
+    a->grid_logically_zero = false;
     return GC_OK;
 }
 
@@ -467,6 +471,11 @@ gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid)
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
     const size_t n = (size_t)a->n_bins * a->fft_size;
+    if (a->grid_logically_zero)
+        {
+            std::memset(host_grid, 0, n * sizeof(float));
+            return GC_OK;
+        }
     GC_HIP(hipStreamSynchronize(a->ctx->stream));
     GC_HIP(hipMemcpy(host_grid, a->d_grid + (size_t)sat * n, n * sizeof(float), hipMemcpyDeviceToHost));
     return GC_OK;

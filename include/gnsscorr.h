@@ -395,7 +395,8 @@ gc_status gc_acq_fft_size(const gc_acq* a, uint32_t* fft_size, uint32_t* consume
 /* pcps_acquisition::set_local_code for satellite slot `sat` (host pointer to
  * consumed_samples complex; fft_size/2 with bit_transition_flag). */
 gc_status gc_acq_set_local_code(gc_acq* a, int sat, const float* code);
-/* Clears the magnitude grids and the dwell counter (new search). */
+/* New search: the dwell counter restarts and the magnitude grids read as zero (the first dwell after a
+ * reset overwrites them; nothing is enqueued by this call, so it needs no stream). */
 gc_status gc_acq_reset(gc_acq* a);
 /* Second step of make_2_steps (pcps_acquisition.cc:771-829, 957-963): enable != 0 switches the search to
  * num_doppler_bins_step2 bins of doppler_step2 Hz centred on doppler_center_hz

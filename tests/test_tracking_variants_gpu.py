@@ -260,3 +260,31 @@ def test_integer_iq_formats_equal_float_path_on_converted_samples(gctx, oracle, 
     for k in range(n_ep):
         assert abs(refs[k][1]) > 0.4 * truth[0]["amp"] * scale * n
         assert rel_err(got[k], refs[k], 1) <= TOL
+
+
+@pytest.mark.parametrize("case", ["max_code_length", "huge_code_phase", "zero_code_step", "far_taps", "fast_carrier"])
+def test_parameter_extremes(gctx, oracle, case):
+    """Parameters at the edges of what the kernel accepts; every one must still walk the reference's chip indices
+    (the oracle's are pinned bit for bit) and sum to the oracle's values."""
+    import gnsscorr
+    rng = np.random.Generator(np.random.PCG64(["max_code_length", "huge_code_phase", "zero_code_step", "far_taps", "fast_carrier"].index(case) + 70))
+    n = 6000
+    sig = (rng.standard_normal(n + 16) + 1j * rng.standard_normal(n + 16)).astype(np.complex64)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    L, rem, step, carr = 1023, np.float32(-7.75), np.float32(0.2557), np.float32(0.01)
+    if case == "max_code_length":
+        L = 15936  # largest table the 64 KB LDS window takes (kMaxLdsTableFloats - 64)
+        step = np.float32(2.5)
+    elif case == "huge_code_phase":
+        rem = np.float32(-1.0e6)  # hundreds of code periods away: float32 has 1/16-chip resolution there, as in the reference
+    elif case == "zero_code_step":
+        step = np.float32(0.0)
+    elif case == "far_taps":
+        shifts = np.array([-3000.25, 0.0, 2999.5], np.float32)  # taps several code periods apart: no LDS window, wrapping path
+    elif case == "fast_carrier":
+        carr = np.float32(3.0)  # close to pi rad per sample
+    code = np.sign(rng.standard_normal(L)).astype(np.float32)
+    rec = [gnsscorr.epoch_params(3, 0.7, float(carr), float(rem), float(step), n)]
+    ref = oracle.multicorrelator(sig[3:], code, shifts, np.float32(0.7), carr, rem, step, n)
+    got = _batch_one(gctx, sig, code, shifts, rec)[0]
+    assert np.max(np.abs(got - ref)) <= 2e-5 * np.sqrt(n) + TOL * np.max(np.abs(ref)), (case, got, ref)

@@ -13,6 +13,7 @@
 // (host block image only): high-dynamics rate smoothing, telemetry/secondary-code synchronisation.
 #include "gc_internal.h"
 #include <algorithm>
+#include <cstdlib>
 #include "gc_stream.h"
 #include "trk_device.hpp"
 #include <cstring>
@@ -213,8 +214,9 @@ static __device__ void loop_start(LoopChan& s)
     s.lost_lock_events = 0;
 }
 
-template <int NTAPS>
-__global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
+// THREADS per channel: 1024 when there are few channels (one workgroup per CU), 256 when there are many
+template <int NTAPS, int THREADS>
+__global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
     gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats, const unsigned long long* __restrict__ limits)
 {
     extern __shared__ float lds[];
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopCha
         // cooperative copy of the channel state into LDS
         const unsigned* src = reinterpret_cast<const unsigned*>(&chans[ch]);
         unsigned* dst = reinterpret_cast<unsigned*>(&s);
-        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += TRK_THREADS) dst[i] = src[i];
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += THREADS) dst[i] = src[i];
     }
     __syncthreads();
     if (s.n_taps != NTAPS) return;
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopCha
             __syncthreads();
             if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
 
-            const float2 r = trk_epoch<NTAPS, false, false, GC_IQ_F32>(s.chan, s_p, 0, 1, lds_table_floats, lds);
+            const float2 r = trk_epoch<NTAPS, false, false, GC_IQ_F32, false, false, THREADS>(s.chan, s_p, 0, 1, lds_table_floats, lds);
             if (tid < NTAPS) s_corr[tid] = r;
             __syncthreads();
 
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(TRK_THREADS, 4) void trk_closed_loop_kernel(LoopCha
     {
         unsigned* dst = reinterpret_cast<unsigned*>(&chans[ch]);
         const unsigned* src = reinterpret_cast<const unsigned*>(&s);
-        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += TRK_THREADS) dst[i] = src[i];
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += THREADS) dst[i] = src[i];
     }
 }
 
@@ -457,6 +459,7 @@ struct gc_trk_loop
     float* d_codes = nullptr;
     gc_loop_record* d_recs = nullptr;
     size_t recs_cap = 0;
+    int forced_threads = 0;  // $GNSSCORR_LOOP_THREADS (256 / 512 / 1024): tuning knob
     std::vector<char> started;
     std::vector<const void*> iq;
     std::vector<unsigned long long> n_iq;
@@ -482,6 +485,11 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
     l->ctx_ref.bind(ctx);
     l->n_channels = n_channels;
     l->max_code_len = max_code_length;
+    if (const char* e = std::getenv("GNSSCORR_LOOP_THREADS"))
+        {
+            const int v = std::atoi(e);
+            if (v == 256 || v == 512 || v == 1024) l->forced_threads = v;
+        }
     hipError_t e1 = hipMalloc(&l->d_chans, sizeof(LoopChan) * n_channels);
     hipError_t e2 = hipMalloc(&l->d_codes, sizeof(float) * (size_t)n_channels * max_code_length);
     if (e1 != hipSuccess || e2 != hipSuccess)
@@ -669,11 +677,26 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
         }
     const unsigned long long* limits = any_ring ? l->d_limits : nullptr;
     const int lds_table_floats = l->max_code_len + 64;
-    const size_t lds_bytes = (size_t)(TRK_HDR_FLOATS + lds_table_floats) * sizeof(float);
+    // few channels: more threads each, so that a channel's epoch is spread over a whole CU (measured, 256 channels x 64
+    // epochs on 256 CUs: 0.89 / 0.65 / 0.69 ms with 256 / 512 / 1024 threads)
+    const int n_cus = l->ctx->n_cus > 0 ? l->ctx->n_cus : 256;
+    const int threads = l->forced_threads ? l->forced_threads : (2 * l->n_channels <= n_cus ? 1024 : l->n_channels <= 2 * n_cus ? 512 : 256);
+    const size_t lds_bytes = (size_t)(trk_hdr_floats(threads) + lds_table_floats) * sizeof(float);
+#define LAUNCH_LOOP(NT, TH) \
+    hipLaunchKernelGGL((trk_closed_loop_kernel<NT, TH>), dim3(l->n_channels), dim3(TH), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits)
     if (l->n_taps == 5)
-        hipLaunchKernelGGL((trk_closed_loop_kernel<5>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits);
+        {
+            if (threads == 1024) LAUNCH_LOOP(5, 1024);
+            else if (threads == 512) LAUNCH_LOOP(5, 512);
+            else LAUNCH_LOOP(5, 256);
+        }
     else
-        hipLaunchKernelGGL((trk_closed_loop_kernel<3>), dim3(l->n_channels), dim3(TRK_THREADS), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits);
+        {
+            if (threads == 1024) LAUNCH_LOOP(3, 1024);
+            else if (threads == 512) LAUNCH_LOOP(3, 512);
+            else LAUNCH_LOOP(3, 256);
+        }
+#undef LAUNCH_LOOP
     GC_HIP(hipGetLastError());
     for (size_t k = 0; k < rings.size(); k++)
         {

@@ -11,6 +11,8 @@
 #define TRK_THREADS 256
 #define TRK_CHUNK 512  // samples per workgroup iteration (2 per lane)
 #define TRK_HDR_FLOATS 64
+// LDS header of a workgroup of `threads` threads: one (re, im) partial per wave and tap (GC_MAX_TAPS taps)
+static constexpr __host__ __device__ int trk_hdr_floats(int threads) { return threads / 64 * 16; }
 #define TRK_RESYNC 64  // iterations between exact re-evaluations of the carrier phase
 #ifndef TRK_PF
 #define TRK_PF 2  // chunks prefetched ahead of the one being processed (16-byte loads in flight per lane)
@@ -153,12 +155,14 @@ static __device__ __forceinline__ int floor_to_int(float x)
 //             sample is rounded to int16, multiplied with an int16 complex chip (wrapping to int16 like the
 //             reference's lv_16sc_t product) and accumulated in 32-bit integers; the table holds one
 //             (re16, im16) pair per 4-byte word and the accumulators carry integer bit patterns
-template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false, bool SC16 = false>
+//   THREADS : workgroup size (a multiple of 64); a chunk is 2*THREADS samples
+template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS>
 static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
     int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
     float (&accr)[NTAPS], float (&acci)[NTAPS])
 {
+    constexpr int CHUNK = 2 * THREADS;
     const int tid = threadIdx.x;
     const float* tl = table - (CC ? 2 * lo : lo);  // windowed lookups index with the unwrapped chip number
     // one tap, one sample: acc += y * code[i]
@@ -190,11 +194,11 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
             }
     };
 
-    // per-chunk advance of the two per-lane rotators: exp(j*TRK_CHUNK*dtheta)
+    // per-chunk advance of the two per-lane rotators: exp(j*CHUNK*dtheta)
     float wr = 1.0f, wi = 0.0f;
     if (!HDC)
         {
-            double t = (double)TRK_CHUNK * dtheta * 0.15915494309189533577;
+            double t = (double)CHUNK * dtheta * 0.15915494309189533577;
             t -= rint(t);
             sincosf((float)(t * 6.283185307179586477), &wi, &wr);
         }
@@ -211,11 +215,11 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     // A chunk is "full" when every lane's two samples lie inside the window: plain 16-byte loads, no
     // masks, no clamps.  Only the first chunk (odd-aligned window) and the last one can be ragged; they
     // are processed outside the pipelined interior loop.
-    auto chunk_is_full = [&](int c) { return (c > 0 || a == 0) && (c + 1) * TRK_CHUNK <= V; };
+    auto chunk_is_full = [&](int c) { return (c > 0 || a == 0) && (c + 1) * CHUNK <= V; };
     auto load_full = [&](int c) -> f32x4 {
         // uniform chunk base + constant per-lane offset: SGPR-base global loads
         typedef typename IqFmt<FMT>::pair pair_t;
-        const GC_GLOBAL char* p = reinterpret_cast<const GC_GLOBAL char*>(base) + (size_t)c * (TRK_CHUNK / 2 * sizeof(pair_t)) + tid * sizeof(pair_t);
+        const GC_GLOBAL char* p = reinterpret_cast<const GC_GLOBAL char*>(base) + (size_t)c * (CHUNK / 2 * sizeof(pair_t)) + tid * sizeof(pair_t);
 #if TRK_NT
         return IqFmt<FMT>::cvt(__builtin_nontemporal_load(reinterpret_cast<const GC_GLOBAL pair_t*>(p)));
 #else
@@ -223,7 +227,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 #endif
     };
     auto load_masked = [&](int c) -> f32x4 {
-        const int v = c * TRK_CHUNK + tid * 2;
+        const int v = c * CHUNK + tid * 2;
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
         if (v >= a && v < V)
             {
@@ -243,7 +247,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     auto resync = [&](int c) {
         if (!HDC)
             {
-                const int v = c * TRK_CHUNK + tid * 2;
+                const int v = c * CHUNK + tid * 2;
                 carrier_at<false>(v - a, theta0, dtheta, 0.0, z0r, z0i);
                 z1r = fmaf(z0r, w1r, -(z0i * w1i));
                 z1i = fmaf(z0r, w1i, z0i * w1r);
@@ -252,7 +256,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     // one chunk of work, then one step of the rotators
     auto process = [&](auto full_tag, int c, const f32x4 xc) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const int v = c * TRK_CHUNK + tid * 2;
+        const int v = c * CHUNK + tid * 2;
         int n0 = v - a, n1 = v + 1 - a;
         if (!FULL)
             {
@@ -392,14 +396,16 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 
 // One (channel, epoch, slice): builds the LDS code window, streams the IQ window, reduces the tap sums.
 // Every thread of the 256-thread workgroup must call it; the sum of tap `tid` is returned to the threads
-// with tid < NTAPS (others get 0).  lds: TRK_HDR_FLOATS + lds_table_floats floats of dynamic LDS.
+// with tid < NTAPS (others get 0).  lds: trk_hdr_floats(THREADS) + lds_table_floats floats of dynamic LDS.
 // With SC16 the returned pair holds the two 32-bit integer sums as bit patterns.
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false>
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
     int lds_table_floats, float* lds)
 {
-    // lds[0..63]: header (wave partials); lds[64..]: code window
-    float* table = lds + TRK_HDR_FLOATS;
+    // lds[0..HDRF): header (wave partials); then the code window
+    constexpr int CHUNK = 2 * THREADS;
+    constexpr int HDRF = trk_hdr_floats(THREADS);
+    float* table = lds + HDRF;
     const int tid = threadIdx.x;
     const int N = p.n_samples;
     const int L = cd.code_len;
@@ -410,7 +416,7 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
     // pair-aligned; sample n lives at base[n + a].  IQ lives in HBM: global (not flat) loads
     const GC_GLOBAL elem_t* base = (const GC_GLOBAL elem_t*)(iq - a);
     const int V = N + a;
-    const int n_chunks = (V + TRK_CHUNK - 1) / TRK_CHUNK;
+    const int n_chunks = (V + CHUNK - 1) / CHUNK;
     const int cps = (n_chunks + n_slices - 1) / n_slices;
     const int c0 = slice * cps;
     const int c1 = min(n_chunks, c0 + cps);
@@ -473,8 +479,8 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
         }
     else
         {
-            n_lo = max(c0 * TRK_CHUNK - a, 0);
-            n_hi = max(min(c1 * TRK_CHUNK - a, N) - 1, n_lo);
+            n_lo = max(c0 * CHUNK - a, 0);
+            n_hi = max(min(c1 * CHUNK - a, N) - 1, n_lo);
         }
     float smin = shifts[0], smax = shifts[0];
     if (!HDR)
@@ -512,7 +518,7 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
             const int cbase = posmod(lo, L);
             if (cbase + span <= 3 * L)
                 {
-                    for (int k = tid; k < span; k += TRK_THREADS)
+                    for (int k = tid; k < span; k += THREADS)
                         {
                             int i = cbase + k;  // < 3L: two conditional subtractions instead of a division
                             i = (i >= L) ? i - L : i;
@@ -522,12 +528,12 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
                 }
             else
                 {
-                    for (int k = tid; k < span; k += TRK_THREADS) table_c[k] = code[(cbase + k) % L];
+                    for (int k = tid; k < span; k += THREADS) table_c[k] = code[(cbase + k) % L];
                 }
         }
     else
         {
-            for (int k = tid; k < L; k += TRK_THREADS) table_c[k] = code[k];
+            for (int k = tid; k < L; k += THREADS) table_c[k] = code[k];
         }
     __syncthreads();
 
@@ -536,9 +542,9 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
     for (int t = 0; t < NTAPS; t++) accr[t] = acci[t] = 0.0f;
 
     if (windowed)
-        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
     else
-        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread
@@ -569,7 +575,7 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
         {
             float sr = 0.f, si = 0.f;
 #pragma unroll
-            for (int w = 0; w < TRK_THREADS / 64; w++)
+            for (int w = 0; w < THREADS / 64; w++)
                 {
                     if (SC16)
                         {

@@ -247,6 +247,10 @@ def main():
     result = None
     if rank == 0:
         extra = {}
+        # the extras below are single-GPU side measurements: in a multi-GPU run the other ranks would only wait for them
+        if world > 1:
+            args.no_shared = True
+            args.no_acq = True
         # ---- shared-stream mode: all 32 channels on ONE RF stream (cache-served) ----
         if not args.no_shared:
             for ch in range(N_CHANNELS):

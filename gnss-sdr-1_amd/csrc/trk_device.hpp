@@ -8,9 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
-#define TRK_THREADS 256
-#define TRK_CHUNK 512  // samples per workgroup iteration (2 per lane)
-#define TRK_HDR_FLOATS 64
+#ifndef TRK_THREADS
+#define TRK_THREADS 256  // workgroup size of the open-loop kernel (512 / 1024 measured: no faster)
+#endif
+#define TRK_CHUNK (2 * TRK_THREADS)  // samples per workgroup iteration (2 per lane)
+#define TRK_HDR_FLOATS (TRK_THREADS / 64 * 16)
 // LDS header of a workgroup of `threads` threads: one (re, im) partial per wave and tap (GC_MAX_TAPS taps)
 static constexpr __host__ __device__ int trk_hdr_floats(int threads) { return threads / 64 * 16; }
 #define TRK_RESYNC 64  // iterations between exact re-evaluations of the carrier phase

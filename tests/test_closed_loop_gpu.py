@@ -99,3 +99,48 @@ def test_closed_loop_many_channels_and_restart(gctx, oracle):
         assert abs(one["carrier_doppler_hz"][ch, -20:].mean() - truth[ch]["doppler"]) < 6.0
         p = one["corr"][ch, -20:, 2] + 1j * one["corr"][ch, -20:, 3]
         assert np.mean(np.abs(p)) > 0.6 * truth[ch]["amp"] * 4000
+
+
+def test_closed_loop_galileo_e1_veml(gctx, oracle):
+    """Five-tap VE/E/P/L/VL loop of Galileo E1 (sinBOC(1,1) replica at 2 samples per chip, 4 ms code period, the VEML
+    discriminator of dll_veml..., tracking_discriminators.cc:113-128) against the CPU restatement."""
+    import os
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    code = oracle.galileo_e1_sinboc11(e1b[4])  # 8184 half-chips
+    fs, n, n_ep = 4e6, 16000, 40
+    doppler, delay = -1234.0, 5000.0
+    rng = np.random.Generator(np.random.PCG64(88))
+    i = np.arange(n * (n_ep + 3))
+    rate = 2.046e6 * (1 + doppler / 1575.42e6) / fs  # half-chips per sample
+    tau0 = 8184.0 - delay * 2.046e6 / fs
+    chip = np.floor(tau0 + i * rate).astype(np.int64) % 8184
+    amp = np.sqrt(10 ** (45.0 / 10) / fs)
+    x = (amp * code[chip] * np.exp(1j * (2 * np.pi * doppler * i / fs + 1.1)) + (rng.standard_normal(i.size) + 1j * rng.standard_normal(i.size)) * np.sqrt(0.5)).astype(np.complex64)
+    conf = dict(fs_in=fs, signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=1.023e6, code_period_s=0.004, carrier_lock_th=0.85,
+        code_length_chips=4092, code_samples_per_chip=2, vector_length=n, pull_in_time_s=2, veml=1, pll_filter_order=3, dll_filter_order=2,
+        enable_fll_pull_in=0, enable_fll_steady_state=0, cn0_samples=10, cn0_min=25, max_lock_fail=50, pll_bw_hz=15.0, dll_bw_hz=0.75, fll_bw_hz=10.0,
+        early_late_space_chips=0.15, very_early_late_space_chips=0.6, acq_delay_samples=delay, acq_doppler_hz=doppler + 4.0,
+        acq_samplestamp_samples=0, sample_counter=0)
+    ref = ref_run(oracle, x, code, conf, n_ep)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 8184)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    assert len(ref) == n_ep and np.all(rec["valid"] == 1)
+    for k in range(n_ep):
+        r, g = ref[k], rec[k]
+        assert int(g["sample_counter"]) == r["sample_counter"], k
+        gp = g["corr"][4] + 1j * g["corr"][5]
+        assert abs(gp - r["corr"][2]) <= 2e-3 * abs(r["corr"][2])
+        assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.05
+        assert abs(float(g["code_error_chips"]) - r["cerr"]) < 2e-3
+    # prompt on the BOC main peak, E/L 0.15 chip off (~70 % of it), VE/VL 0.6 chip off (near the BOC side lobes' zero)
+    m = np.abs(rec["corr"][-10:, 0::2] + 1j * rec["corr"][-10:, 1::2]).mean(axis=0)
+    assert m[2] > m[1] > m[0] and m[2] > m[3] > m[4]
+    assert abs(rec["carrier_doppler_hz"][-10:].mean() - doppler) < 3.0

@@ -329,6 +329,45 @@ def main():
                 "note": "32 channels, 25 Msps, 5 taps, L = 8184, N = 100000 (4 ms), distinct IQ buffer per channel"}
             bg.close()
 
+        # ---- BASELINE configs[4] per-GPU share: 32 channels = 16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I ----
+        if not args.no_shared:
+            rng_h = np.random.Generator(np.random.PCG64(1005))
+            hb = []  # (batch, n_epochs, params, out, samples)
+            def add_group(first_ch, n_ch, n_taps, L, n_len, step_chips, hshifts):
+                b = gnsscorr.TrackingBatch(ctx, n_ch, n_taps, L)
+                n_ep = max(1, (E * N_EPOCH) // n_len)
+                recs = []
+                for k in range(n_ch):
+                    b.set_code(k, np.sign(rng_h.standard_normal(L)).astype(np.float32), hshifts)
+                    b.set_input_dev(k, streams[first_ch + k].data_ptr(), n_stream)
+                    recs.append([gnsscorr.epoch_params(e * n_len, 0.1, 1e-3, 0.3, float(np.float32(step_chips)), n_len) for e in range(n_ep)])
+                d_p = torch.from_numpy(gnsscorr.epoch_params_array(recs).view(np.uint8)).to(dev)
+                d_o = torch.zeros(n_ch * n_ep * n_taps, 2, device=dev, dtype=torch.float32)
+                hb.append((b, n_ep, d_p, d_o, n_ch * n_ep * n_len))
+            add_group(0, 16, 3, 1023, N_EPOCH, 1.023e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
+            add_group(16, 8, 5, 8184, 4 * N_EPOCH, 2.046e6 / FS, np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32))
+            add_group(24, 8, 3, 2046, N_EPOCH, 2.046e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
+            def hybrid_step():
+                for b, n_ep, d_p, d_o, _ in hb:
+                    b.run_dev(n_ep, d_p.data_ptr(), d_o.data_ptr(), stream)
+            for _ in range(2):
+                hybrid_step()
+            torch.cuda.synchronize()
+            h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            h0.record()
+            for _ in range(args.steps):
+                hybrid_step()
+            h1.record()
+            torch.cuda.synchronize()
+            hyb_ms = h0.elapsed_time(h1) / args.steps
+            hyb_samples = sum(g[4] for g in hb)
+            extra["hybrid_gps_galileo_beidou"] = {"value": hyb_samples / (hyb_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": hyb_ms,
+                "hbm_gbps": 8.0 * hyb_samples / (hyb_ms * 1e-3) / 1e9, "realtime_factor_32ch": hyb_samples / (hyb_ms * 1e-3) / (32 * FS),
+                "note": "one GPU's share of the 256-channel hybrid: 16 GPS L1 C/A (3 taps) + 8 Galileo E1 (5 taps, L = 8184, 4 ms) + 8 BeiDou B1I "
+                        "(3 taps, L = 2046), 25 Msps, distinct IQ buffer per channel, three launches per step"}
+            for g in hb:
+                g[0].close()
+
         # ---- host-fed pipeline: one RF stream pushed over PCIe into the HBM ring while the channels track it ----
         if not args.no_shared:
             blk_epochs = 16

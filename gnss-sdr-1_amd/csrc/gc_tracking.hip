@@ -171,6 +171,8 @@ gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int 
     if (b->complex_codes) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code: the batch holds complex codes (gc_trk_batch_set_code_complex)");
     if (b->sc16) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code: the batch is in 16-bit mode (gc_trk_batch_set_code_16sc)");
     gc_device_guard g(b->ctx->device);
+    std::lock_guard<std::mutex> lk(b->ctx->mtx);
+    GC_HIP(hipStreamSynchronize(b->ctx->stream));  // launches on the context's stream may still read the old table
     GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * b->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
     b->h_chans[ch].code_len = code_length;
     return gc_trk_batch_set_shifts(b, ch, shifts_chips);
@@ -216,6 +218,8 @@ gc_status gc_trk_batch_set_code_complex(gc_trk_batch* b, int ch, const float* co
         code_length, b->max_code_len);
     if (!b->complex_codes) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code_complex: call gc_trk_batch_set_complex_codes(batch, 1) first");
     gc_device_guard g(b->ctx->device);
+    std::lock_guard<std::mutex> lk(b->ctx->mtx);
+    GC_HIP(hipStreamSynchronize(b->ctx->stream));
     GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * 2 * b->max_code_len, code_iq, sizeof(float) * 2 * code_length, hipMemcpyHostToDevice));
     b->h_chans[ch].code_len = code_length;
     return gc_trk_batch_set_shifts(b, ch, shifts_chips);
@@ -228,6 +232,7 @@ gc_status gc_trk_batch_set_16sc(gc_trk_batch* b, int on)
     if (want == b->sc16) return GC_OK;
     if (want && b->mode != TRK_MODE_PLAIN)
         return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_16sc: not available with high dynamics or complex float codes");
+    b->sc16 = false;  // the format setter refuses anything but cshort while the flag is up
     gc_status s = gc_trk_batch_set_input_format(b, want ? GC_IQ_I16 : GC_IQ_F32);  // drops the registered inputs
     if (s != GC_OK) return s;
     for (auto& c : b->h_chans) c.code_len = 0;  // every channel needs its code again (4 bytes per chip either way)
@@ -245,6 +250,8 @@ gc_status gc_trk_batch_set_code_16sc(gc_trk_batch* b, int ch, const int16_t* cod
         code_length, b->max_code_len);
     if (!b->sc16) return gc_fail(GC_ERR_STATE, "gc_trk_batch_set_code_16sc: call gc_trk_batch_set_16sc(batch, 1) first");
     gc_device_guard g(b->ctx->device);
+    std::lock_guard<std::mutex> lk(b->ctx->mtx);
+    GC_HIP(hipStreamSynchronize(b->ctx->stream));
     GC_HIP(hipMemcpy(b->d_codes + (size_t)ch * b->max_code_len, code_iq, sizeof(int16_t) * 2 * code_length, hipMemcpyHostToDevice));
     b->h_chans[ch].code_len = code_length;
     return gc_trk_batch_set_shifts(b, ch, shifts_chips);

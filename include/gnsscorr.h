@@ -206,7 +206,10 @@ gc_status gc_trk_batch_create(gc_ctx* ctx, int n_channels, int n_taps, int max_c
     int high_dyn, gc_trk_batch** out);
 gc_status gc_trk_batch_destroy(gc_trk_batch* b);
 /* Uploads channel `ch`'s code table (float[code_length], +-1 or any real
- * replica) and tap shifts (float[n_taps], in code samples). (host pointers) */
+ * replica) and tap shifts (float[n_taps], in code samples). (host pointers)
+ * Setters take effect at the next run call; they wait for launches on the
+ * context's own stream, but launches still in flight on a CALLER stream
+ * (gc_trk_batch_run_dev) must be synchronised by the caller first. */
 gc_status gc_trk_batch_set_code(gc_trk_batch* b, int ch, const float* code, int code_length,
     const float* shifts_chips);
 gc_status gc_trk_batch_set_shifts(gc_trk_batch* b, int ch, const float* shifts_chips);

@@ -136,4 +136,7 @@ def test_16sc_state_errors(gctx):
         b.set_input_format(gnsscorr.GC_IQ_F32)
     with pytest.raises(gnsscorr.GnsscorrError):
         b.set_code(0, np.ones(1023, np.float32), np.zeros(3, np.float32))
+    b.set_16sc(False)  # back to the float correlator: float codes and any input format are accepted again
+    b.set_code(0, np.ones(1023, np.float32), np.zeros(3, np.float32))
+    b.set_input_format(gnsscorr.GC_IQ_I8)
     b.close()

@@ -516,7 +516,8 @@ def main():
                 "parallelism": "channels sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "trk_multicorrelator_kernel<3,false,false>", "kernel_ms": kernel_ms,
+                # <NTAPS, HDR, HDC, FMT = GC_IQ_F32, CC, SC16>: the name rocprofv3 prints
+                "kernel": "trk_multicorrelator_kernel<3, false, false, 0, false, false>", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }

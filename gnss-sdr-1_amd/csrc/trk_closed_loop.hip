@@ -215,7 +215,7 @@ static __device__ void loop_start(LoopChan& s)
 }
 
 // THREADS per channel: 1024 when there are few channels (one workgroup per CU), 256 when there are many
-template <int NTAPS, int THREADS>
+template <int NTAPS, int THREADS, int FMT>
 __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
     gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats, const unsigned long long* __restrict__ limits)
 {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
             __syncthreads();
             if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
 
-            const float2 r = trk_epoch<NTAPS, false, false, GC_IQ_F32, false, false, THREADS>(s.chan, s_p, 0, 1, lds_table_floats, lds);
+            const float2 r = trk_epoch<NTAPS, false, false, FMT, false, false, THREADS>(s.chan, s_p, 0, 1, lds_table_floats, lds);
             if (tid < NTAPS) s_corr[tid] = r;
             __syncthreads();
 
@@ -460,6 +460,7 @@ struct gc_trk_loop
     gc_loop_record* d_recs = nullptr;
     size_t recs_cap = 0;
     int forced_threads = 0;  // $GNSSCORR_LOOP_THREADS (256 / 512 / 1024): tuning knob
+    int iq_format = GC_IQ_F32;  // sample format of every channel's input (gc_trk_loop_set_input_format)
     std::vector<char> started;
     std::vector<const void*> iq;
     std::vector<unsigned long long> n_iq;
@@ -539,7 +540,8 @@ gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, 
 {
     GC_REQUIRE(l && dev_iq, "gc_trk_loop_set_input_dev: NULL argument");
     GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_set_input_dev: channel %d out of range", ch);
-    GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) & 7) == 0, "gc_trk_loop_set_input_dev: IQ pointer must be 8-byte aligned");
+    const uintptr_t es = l->iq_format == GC_IQ_F32 ? 8 : l->iq_format == GC_IQ_I16 ? 4 : 2;
+    GC_REQUIRE((reinterpret_cast<uintptr_t>(dev_iq) % es) == 0, "gc_trk_loop_set_input_dev: IQ pointer must be aligned to one sample (%d bytes)", (int)es);
     gc_device_guard g(l->ctx->device);
     std::lock_guard<std::mutex> lk(l->ctx->mtx);
     if (l->streams[ch]) gc_stream_drop(l->streams[ch]);
@@ -561,12 +563,25 @@ gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, 
     return GC_OK;
 }
 
+gc_status gc_trk_loop_set_input_format(gc_trk_loop* l, int iq_format)
+{
+    GC_REQUIRE(l, "gc_trk_loop_set_input_format: NULL handle");
+    GC_REQUIRE(iq_format == GC_IQ_F32 || iq_format == GC_IQ_I16 || iq_format == GC_IQ_I8, "gc_trk_loop_set_input_format: unknown format %d", iq_format);
+    if (iq_format == l->iq_format) return GC_OK;
+    for (int i = 0; i < l->n_channels; i++)
+        if (l->started[i] || l->iq[i] != nullptr)
+            return gc_fail(GC_ERR_STATE, "gc_trk_loop_set_input_format: set the format before binding inputs or starting channels");
+    l->iq_format = iq_format;
+    return GC_OK;
+}
+
 gc_status gc_trk_loop_set_input_stream(gc_trk_loop* l, int ch, gc_stream* s)
 {
     GC_REQUIRE(l && s, "gc_trk_loop_set_input_stream: NULL argument");
     GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_set_input_stream: channel %d out of range", ch);
     GC_REQUIRE(s->ctx->device == l->ctx->device, "gc_trk_loop_set_input_stream: the stream lives on another GPU");
-    GC_REQUIRE(s->iq_format == GC_IQ_F32, "gc_trk_loop_set_input_stream: the closed-loop engine reads gr_complex streams");
+    GC_REQUIRE(s->iq_format == l->iq_format, "gc_trk_loop_set_input_stream: stream format %d, engine format %d (gc_trk_loop_set_input_format)",
+        s->iq_format, l->iq_format);
     if (l->started[ch]) return gc_fail(GC_ERR_STATE, "gc_trk_loop_set_input_stream: channel %d is running; bind the stream before gc_trk_loop_start", ch);
     std::lock_guard<std::mutex> lk(l->ctx->mtx);
     gc_stream_keep(s);
@@ -682,20 +697,29 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
     const int n_cus = l->ctx->n_cus > 0 ? l->ctx->n_cus : 256;
     const int threads = l->forced_threads ? l->forced_threads : (2 * l->n_channels <= n_cus ? 1024 : l->n_channels <= 2 * n_cus ? 512 : 256);
     const size_t lds_bytes = (size_t)(trk_hdr_floats(threads) + lds_table_floats) * sizeof(float);
-#define LAUNCH_LOOP(NT, TH) \
-    hipLaunchKernelGGL((trk_closed_loop_kernel<NT, TH>), dim3(l->n_channels), dim3(TH), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits)
+#define LAUNCH_LOOP(NT, TH, FM) \
+    hipLaunchKernelGGL((trk_closed_loop_kernel<NT, TH, FM>), dim3(l->n_channels), dim3(TH), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits)
+#define LAUNCH_LOOP_FMT(NT, TH)                                           \
+    do                                                                    \
+        {                                                                 \
+            if (l->iq_format == GC_IQ_I16) LAUNCH_LOOP(NT, TH, GC_IQ_I16); \
+            else if (l->iq_format == GC_IQ_I8) LAUNCH_LOOP(NT, TH, GC_IQ_I8); \
+            else LAUNCH_LOOP(NT, TH, GC_IQ_F32);                          \
+        }                                                                 \
+    while (0)
     if (l->n_taps == 5)
         {
-            if (threads == 1024) LAUNCH_LOOP(5, 1024);
-            else if (threads == 512) LAUNCH_LOOP(5, 512);
-            else LAUNCH_LOOP(5, 256);
+            if (threads == 1024) LAUNCH_LOOP_FMT(5, 1024);
+            else if (threads == 512) LAUNCH_LOOP_FMT(5, 512);
+            else LAUNCH_LOOP_FMT(5, 256);
         }
     else
         {
-            if (threads == 1024) LAUNCH_LOOP(3, 1024);
-            else if (threads == 512) LAUNCH_LOOP(3, 512);
-            else LAUNCH_LOOP(3, 256);
+            if (threads == 1024) LAUNCH_LOOP_FMT(3, 1024);
+            else if (threads == 512) LAUNCH_LOOP_FMT(3, 512);
+            else LAUNCH_LOOP_FMT(3, 256);
         }
+#undef LAUNCH_LOOP_FMT
 #undef LAUNCH_LOOP
     GC_HIP(hipGetLastError());
     for (size_t k = 0; k < rings.size(); k++)

@@ -148,6 +148,7 @@ API = {
     "gc_stream_push_pinned": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gc_stream_info": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gc_stream_synchronize": (C.c_int, [_vp]),
+    "gc_trk_loop_set_input_format": (C.c_int, [_vp, C.c_int]),
     "gc_trk_loop_set_input_stream": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_trk_batch_set_input_stream": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_trk_batch_set_read_floor": (C.c_int, [_vp, C.c_uint64]),
@@ -585,6 +586,9 @@ class TrackingLoop:
 
     def set_input_dev(self, ch, dev_ptr, n_samples):
         _check(load_library().gc_trk_loop_set_input_dev(self._h, ch, _vp(dev_ptr), int(n_samples)))
+
+    def set_input_format(self, iq_format):
+        _check(load_library().gc_trk_loop_set_input_format(self._h, int(iq_format)))
 
     def set_input_stream(self, ch, stream):
         _check(load_library().gc_trk_loop_set_input_stream(self._h, ch, stream._h))

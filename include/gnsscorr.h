@@ -307,9 +307,12 @@ typedef struct
 typedef struct gc_trk_loop gc_trk_loop;
 gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, gc_trk_loop** out);
 gc_status gc_trk_loop_destroy(gc_trk_loop* l);
-/* IQ block of channel `ch` in HBM (gr_complex); epochs are correlated until it is exhausted. */
+/* Sample format of every channel's input (default GC_IQ_F32; cshort / cbyte samples are converted on load like
+ * in the batched engine).  Call before binding inputs. */
+gc_status gc_trk_loop_set_input_format(gc_trk_loop* l, int iq_format);
+/* IQ block of channel `ch` in HBM (samples of the engine's format); epochs are correlated until it is exhausted. */
 gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, uint64_t n_samples);
-/* Channel `ch` reads the RF stream ring `s` (gr_complex) instead of a fixed block: bind before
+/* Channel `ch` reads the RF stream ring `s` (same sample format) instead of a fixed block: bind before
  * gc_trk_loop_start; the channel then starts at absolute sample gc_loop_conf.sample_counter and every launch
  * correlates the code periods that are complete in the ring at that moment (the remaining records of the
  * launch are marked invalid, state unchanged), so "push a block, run" is the whole host loop.

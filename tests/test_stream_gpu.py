@@ -187,3 +187,41 @@ def test_closed_loop_on_the_ring_equals_block_input(gctx, oracle):
         loop.run(1)
     loop.close()
     ring.close()
+
+
+def test_closed_loop_on_a_cshort_ring(gctx, oracle):
+    """The closed-loop engine fed with lv_16sc_t samples (as an SDR front-end delivers them) through a cshort ring:
+    same records as the float engine run on the converted samples."""
+    import gnsscorr
+    import torch
+    from test_closed_loop_gpu import GPS, _conf, _signal
+    fs, n_ep = 4e6, 40
+    code, x = _signal(oracle, 12, fs, 4000 * (n_ep + 3), 66, 905.0, 2100.0)
+    q = np.round(x.view(np.float32).reshape(-1, 2) * 64.0).astype(np.int16)
+    xf = q.astype(np.float32).reshape(-1).view(np.complex64)  # what the cast on load produces
+    conf = dict(GPS, acq_delay_samples=2100.0, acq_doppler_hz=900.0, acq_samplestamp_samples=0, sample_counter=0)
+    d = torch.from_numpy(xf.view(np.float32).copy()).cuda()
+    lin = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    lin.set_input_dev(0, d.data_ptr(), xf.size)
+    lin.start(0, _conf(gnsscorr, **conf), code)
+    want = lin.run(n_ep)[0]
+    lin.close()
+    ring = gnsscorr.IqStream(gctx, capacity_samples=20000, max_window_samples=4000, iq_format=gnsscorr.GC_IQ_I16)
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_format(gnsscorr.GC_IQ_I16)
+    loop.set_input_stream(0, ring)
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    got, pushed = [], 0
+    while len(got) < n_ep and pushed < q.shape[0]:
+        m = min(8000, q.shape[0] - pushed)
+        ring.push(q[pushed:pushed + m])
+        pushed += m
+        got.extend(r.copy() for r in loop.run(3)[0] if r["valid"])
+    got = np.array(got[:n_ep])
+    assert len(got) == n_ep and np.all(want["valid"] == 1)
+    for name in want.dtype.names:
+        assert np.array_equal(got[name], want[name]), name
+    with pytest.raises(gnsscorr.GnsscorrError):
+        loop.set_input_format(gnsscorr.GC_IQ_F32)  # not while channels are bound
+    loop.close()
+    ring.close()

@@ -469,6 +469,14 @@ def main():
             a1.record()
             torch.cuda.synchronize()
             acq_ms = a0.elapsed_time(a1) / reps
+            # sanity: stream 0 carries PRN 1 only -- it must win, at its code phase and in its Doppler bin
+            ares = acq.fetch_results(stream)
+            stats = np.array([r.test_statistics for r in ares])
+            t_a = truths[0]
+            want_delay = ((CODE_LEN - t_a["tau0"]) % CODE_LEN) * FS / 1.023e6
+            d_err = abs(ares[0].indext - want_delay)
+            assert int(np.argmax(stats)) == 0 and min(d_err, N_EPOCH - d_err) <= 26 and abs(ares[0].doppler_hz - t_a["doppler"]) <= 250, \
+                ("acquisition lost PRN 1", stats[:4], ares[0].indext, want_delay, ares[0].doppler_hz, t_a["doppler"])
             extra["acquisition"] = {"dwells_per_s": 64 / (acq_ms * 1e-3), "ms_per_search": acq_ms,
                 "workload": "GPS L1 C/A PCPS, 25 Msps, N=25000, 32 PRNs x 41 Doppler bins x 2 dwells"}
             acq.close()

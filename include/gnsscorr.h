@@ -114,7 +114,8 @@ gc_status gc_correlator_free(gc_correlator* c);
 gc_status gc_correlator_set_local_code_and_taps_complex(gc_correlator* c, int code_length_chips,
     const float* local_code_in_iq, float* shifts_chips);
 /* Cpu_Multicorrelator::Carrier_wipeoff_multicorrelator_resampler, 5 arguments
- * (cpu_multicorrelator.cc:116-130); GC_ERR_STATE unless the code is complex. */
+ * (cpu_multicorrelator.cc:116-130); GC_ERR_STATE unless the code is complex
+ * (float pairs, or lv_16sc_t with the setters below). */
 gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlator* c,
     float rem_carrier_phase_in_rad, float phase_step_rad,
     float rem_code_phase_chips, float code_phase_step_chips,

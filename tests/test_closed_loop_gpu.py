@@ -144,3 +144,32 @@ def test_closed_loop_galileo_e1_veml(gctx, oracle):
     m = np.abs(rec["corr"][-10:, 0::2] + 1j * rec["corr"][-10:, 1::2]).mean(axis=0)
     assert m[2] > m[1] > m[0] and m[2] > m[3] > m[4]
     assert abs(rec["carrier_doppler_hz"][-10:].mean() - doppler) < 3.0
+
+
+def test_closed_loop_declares_loss_of_lock(gctx, oracle):
+    """The satellite disappears mid-stream: cn0_and_tracking_lock_status (dll_pll_veml_tracking.cc:839-878) counts
+    failed lock tests and, past max_lock_fail, the channel goes to standby (state 0) and stops producing valid
+    records -- the device loop's image of the block's "loss of lock" message."""
+    import gnsscorr
+    import torch
+    fs, n_ep = 4e6, 260
+    code, x = _signal(oracle, 21, fs, 4000 * (n_ep + 3), 31, 440.0, 1000.0)
+    rng = np.random.Generator(np.random.PCG64(32))
+    cut = 4000 * 80
+    x[cut:] = ((rng.standard_normal(x.size - cut) + 1j * rng.standard_normal(x.size - cut)) * np.sqrt(0.5)).astype(np.complex64)
+    conf = dict(GPS, acq_delay_samples=1000.0, acq_doppler_hz=445.0, acq_samplestamp_samples=0, sample_counter=0)
+    conf.update(cn0_samples=10, max_lock_fail=5, pull_in_time_s=0)  # the lock counter only runs after the pull-in transitory
+    conf["acq_samplestamp_samples"] = 0
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    # pull_in_time_s = 0 ends the transitory after one second of stream: start the channel's counter one second in
+    c = _conf(gnsscorr, **dict(conf, sample_counter=int(1.1 * fs), acq_samplestamp_samples=int(1.1 * fs) - int(1.05 * fs)))
+    loop.start(0, c, code)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    states = rec["state"]
+    assert np.all(states[:75] == 2) and np.all(rec["valid"][:75] == 1)      # tracking while the signal is there
+    lost = int(np.argmax(states == 0))
+    assert states[lost] == 0 and 80 < lost <= 80 + 11 * (5 + 2) + 11        # ~max_lock_fail failed tests of 11 epochs each
+    assert np.all(states[lost:] == 0) and np.all(rec["valid"][lost:] == 0)   # standby from then on

@@ -13,6 +13,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The built library normally travels with the tree; a fresh checkout builds it once (hipcc cross-compiles gfx950
+    without a GPU, about a minute and a half)."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "gnss-sdr-1_amd", "libgnsscorr.so")):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "gnss-sdr-1_amd", "csrc")])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure only)."""

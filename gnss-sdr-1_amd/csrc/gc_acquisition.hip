@@ -48,6 +48,7 @@ struct gc_acq
     gc_acq_result* d_results = nullptr;
     gc_acq_result* h_results = nullptr;  // pinned
     std::vector<char> code_set;
+    int64_t freq_offset_hz = 0;  // d_old_freq: intermediate frequency / GLONASS FDMA channel offset
     bool grid_logically_zero = true;  // gc_acq_reset() since the last dwell: the grid reads as zeros
 };
 
@@ -70,6 +71,28 @@ static void acq_release(gc_acq* a)
     (void)hipFree(a->d_cvt);
     (void)hipFree(a->d_results);
     if (a->h_results) (void)hipHostFree(a->h_results);
+}
+
+// d_grid_doppler_wipeoffs of the coarse grid: exp(-j*2*pi*(d_old_freq + doppler)/fs * n) with the reference's float32
+// running phase (update_grid_doppler_wipeoffs :371-380, update_local_carrier :296-310); d_old_freq = freq_offset_hz
+static hipError_t acq_build_main_wipeoffs(gc_acq* a, hipStream_t st)
+{
+    std::vector<float> inc(a->n_bins_main);
+    for (uint32_t d = 0; d < a->n_bins_main; d++)
+        {
+            const int32_t doppler = -(int32_t)a->conf.doppler_max + (int32_t)a->conf.doppler_step * (int32_t)d;
+            const float freq = (float)(a->freq_offset_hz + (int64_t)doppler);
+            const float phase_step_rad = (float)(6.283185307179586 * freq / (float)a->conf.fs_in);
+            inc[d] = -phase_step_rad;
+        }
+    float* d_inc = nullptr;
+    hipError_t e = hipMalloc(&d_inc, sizeof(float) * a->n_bins_main);
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(d_inc, inc.data(), sizeof(float) * a->n_bins_main, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe_main, (int)a->n_bins_main, (int)a->fft_size);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_inc);
+    return e;
 }
 
 #define ACQ_TRY(call)                                                                                  \
@@ -181,20 +204,8 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     }
     // Doppler wipe-off grid: init() (:340-357) + update_local_carrier (:296-310)
     {
-        std::vector<float> inc(a->n_bins);
-        for (uint32_t d = 0; d < a->n_bins; d++)
-            {
-                int32_t doppler = -(int32_t)conf->doppler_max + (int32_t)conf->doppler_step * (int32_t)d;
-                float freq = (float)doppler;
-                float phase_step_rad = (float)(6.283185307179586 * freq / (float)conf->fs_in);
-                inc[d] = -phase_step_rad;
-            }
-        float* d_inc = nullptr;
-        ACQ_TRY(hipMalloc(&d_inc, sizeof(float) * a->n_bins));
-        hipError_t e = hipMemcpy(d_inc, inc.data(), sizeof(float) * a->n_bins, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe, (int)a->n_bins, (int)N);
+        hipError_t e = acq_build_main_wipeoffs(a, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(d_inc);
         ACQ_TRY(e);
     }
     ACQ_TRY(hipMemsetAsync(a->d_grid, 0, (size_t)n_sats * a->n_bins_alloc * N * sizeof(float), st));
@@ -253,6 +264,19 @@ gc_status gc_acq_set_local_code(gc_acq* a, int sat, const float* code)
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_local_code: %s", hipGetErrorString(e));
     GC_HIP(hipStreamSynchronize(st));  // buf goes out of scope
     a->code_set[sat] = 1;
+    return GC_OK;
+}
+
+gc_status gc_acq_set_frequency_offset(gc_acq* a, int64_t offset_hz)
+{
+    GC_REQUIRE(a, "gc_acq_set_frequency_offset: NULL handle");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    if (offset_hz == a->freq_offset_hz) return GC_OK;
+    GC_HIP(hipStreamSynchronize(a->ctx->stream));
+    a->freq_offset_hz = offset_hz;
+    hipError_t e = acq_build_main_wipeoffs(a, a->ctx->stream);
+    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_frequency_offset: %s", hipGetErrorString(e));
     return GC_OK;
 }
 

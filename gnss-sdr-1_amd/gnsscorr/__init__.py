@@ -152,6 +152,7 @@ API = {
     "gc_trk_loop_set_input_stream": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_trk_batch_set_input_stream": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_trk_batch_set_read_floor": (C.c_int, [_vp, C.c_uint64]),
+    "gc_acq_set_frequency_offset": (C.c_int, [_vp, C.c_int64]),
     "gc_acq_dwell_stream": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "gc_trk_batch_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gc_trk_batch_destroy": (C.c_int, [_vp]),
@@ -658,6 +659,9 @@ class PcpsAcquisition:
         res = (AcqResult * self.n_sats)()
         _check(load_library().gc_acq_dwell(self._h, iq.view(np.float32).ctypes.data_as(_fp), res))
         return list(res)
+
+    def set_frequency_offset(self, offset_hz):
+        _check(load_library().gc_acq_set_frequency_offset(self._h, int(offset_hz)))
 
     def dwell_stream(self, stream, first_index):
         res = (AcqResult * self.n_sats)()

@@ -402,6 +402,11 @@ gc_status gc_acq_fft_size(const gc_acq* a, uint32_t* fft_size, uint32_t* consume
 /* pcps_acquisition::set_local_code for satellite slot `sat` (host pointer to
  * consumed_samples complex; fft_size/2 with bit_transition_flag). */
 gc_status gc_acq_set_local_code(gc_acq* a, int sat, const float* code);
+/* d_old_freq of the reference (pcps_acquisition.cc:242-247, :276-293, :371-380): a frequency added to every bin of
+ * the coarse Doppler grid -- an intermediate frequency, or the GLONASS FDMA channel offset DFRQ1_GLO * k the reference
+ * installs in set_local_code() for "1G" / "2G" signals.  Rebuilds the wipe-off table (float32 running phase);
+ * reported Doppler values stay relative to the offset, as in the reference.  Default 0. */
+gc_status gc_acq_set_frequency_offset(gc_acq* a, int64_t offset_hz);
 /* New search: the dwell counter restarts and the magnitude grids read as zero (the first dwell after a
  * reset overwrites them; nothing is enqueued by this call, so it needs no stream). */
 gc_status gc_acq_reset(gc_acq* a);

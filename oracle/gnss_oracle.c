@@ -676,6 +676,19 @@ orc_pcps* orc_pcps_create(int64_t fs_in, uint32_t sampled_ms, uint32_t ms_per_co
     return p;
 }
 
+void orc_pcps_set_frequency_offset(orc_pcps* p, int64_t old_freq)
+{
+    /* set_local_code's FDMA branch (:242-247) -> update_grid_doppler_wipeoffs (:371-380): d_old_freq + doppler */
+    for (uint32_t d = 0; d < p->num_doppler_bins; d++)
+        {
+            int32_t doppler = -p->doppler_max + p->doppler_step * (int32_t)d;
+            float freq = (float)(old_freq + (int64_t)doppler);
+            float phase_step_rad = (float)(6.283185307179586 * freq / (float)p->fs_in);
+            float ph = 0.0f;
+            orc_sincos(p->wipeoffs + 2 * (size_t)d * p->fft_size, -phase_step_rad, &ph, p->fft_size);
+        }
+}
+
 void orc_pcps_destroy(orc_pcps* p)
 {
     if (!p) return;

@@ -177,6 +177,9 @@ orc_pcps* orc_pcps_create(int64_t fs_in, uint32_t sampled_ms, uint32_t ms_per_co
     uint32_t doppler_max, uint32_t doppler_step, uint32_t max_dwells,
     int bit_transition_flag, int use_cfar);
 void orc_pcps_destroy(orc_pcps* p);
+/* d_old_freq (intermediate frequency / GLONASS FDMA offset): regenerates the coarse wipe-off grid
+ * (pcps_acquisition.cc:242-247, :371-380) */
+void orc_pcps_set_frequency_offset(orc_pcps* p, int64_t old_freq);
 /* pcps_acquisition::set_local_code (:239-274); code: consumed_samples (or
  * fft_size/2 with bit transition) complex samples */
 void orc_pcps_set_local_code(orc_pcps* p, const float* code);

@@ -110,6 +110,7 @@ class Oracle:
         L.orc_pcps_set_local_code.argtypes = [C.POINTER(_PcpsStruct), c_float_p]
         L.orc_pcps_core.argtypes = [C.POINTER(_PcpsStruct), c_float_p, C.POINTER(PcpsResult)]
         L.orc_pcps_reset_grid.argtypes = [C.POINTER(_PcpsStruct)]
+        L.orc_pcps_set_frequency_offset.argtypes = [C.POINTER(_PcpsStruct), C.c_int64]
 
     # -- tracking ---------------------------------------------------------
     def resampler_indices(self, rem, step, shifts, L, N, rate=None):
@@ -268,6 +269,9 @@ class Pcps:
 
     def reset_grid(self):
         self.orc.lib.orc_pcps_reset_grid(self.p)
+
+    def set_frequency_offset(self, old_freq_hz):
+        self.orc.lib.orc_pcps_set_frequency_offset(self.p, int(old_freq_hz))
 
     def grid(self):
         s = self.p.contents

@@ -236,3 +236,35 @@ def test_fft_sizes_against_oracle(gctx, oracle, n):
     grid, ref = acq.grid(0), p.grid()
     assert np.max(np.abs(grid - ref)) <= TOL * ref.max()
     acq.close()
+
+
+def test_frequency_offset_glonass_fdma(gctx, oracle):
+    """d_old_freq: the GLONASS FDMA channel offset the reference adds to every Doppler bin in set_local_code()
+    (pcps_acquisition.cc:242-247, :276-293, :371-380).  A 511-chip GLONASS-shaped code on frequency channel k = +3
+    (3 x 562500 Hz away from the L1 centre) is found at its true Doppler once the offset is installed."""
+    import gnsscorr
+    fs, n = 8_000_000, 8000
+    rng = np.random.Generator(np.random.PCG64(511))
+    chips = np.sign(rng.standard_normal(511)).astype(np.float32)
+    k_channel, dfrq1 = 3, 562500
+    doppler, delay = -1830.0, 2345
+    i = np.arange(n)
+    idx = np.floor((i - delay) * 0.511e6 / fs).astype(np.int64) % 511
+    x = (0.15 * chips[idx] * np.exp(2j * np.pi * (k_channel * dfrq1 + doppler) * i / fs)
+        + (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.sqrt(0.5)).astype(np.complex64)
+    code = chips[np.floor(i * 0.511e6 / fs).astype(np.int64) % 511].astype(np.complex64)
+    c = dict(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=float(n),
+        samples_per_chip=16, doppler_max=5000, doppler_step=250)
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, **c)
+    acq.set_local_code(0, code)
+    r0 = acq.dwell(x)[0]            # without the offset the satellite is 1.7 MHz outside the grid
+    acq.reset()
+    acq.set_frequency_offset(k_channel * dfrq1)
+    r = acq.dwell(x)[0]
+    p = oracle.pcps(**c)
+    p.set_local_code(code)
+    p.set_frequency_offset(k_channel * dfrq1)
+    q = p.core(x)
+    _check(r, q)
+    assert r.indext == delay and abs(r.doppler_hz - doppler) <= 250 and r.test_statistics > 3 * r0.test_statistics  # 1 ms: the peak is one bin wide
+    acq.close()

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <map>
 #include <mutex>
 #include <string>
 #include <sys/stat.h>
@@ -128,6 +129,7 @@ public:
         c.doppler_step2 = acq_parameters.doppler_step2;
         gc_ctx* ctx = gnsscorr::shared_context();
         d_status = ctx ? gc_acq_create(ctx, &c, 1, &d_acq) : GC_ERR_NO_DEVICE;
+        if (d_status == GC_OK && d_old_freq != 0) d_status = gc_acq_set_frequency_offset(d_acq, d_old_freq);
         if (d_status == GC_OK && !d_code.empty()) d_status = gc_acq_set_local_code(d_acq, 0, reinterpret_cast<const float*>(d_code.data()));
         d_worker_active = false;
         if (d_dump)
@@ -139,10 +141,23 @@ public:
             }
     }
 
+    /*! GLONASS slot -> frequency channel number, what GLONASS_PRN holds in the reference
+     *  (src/core/system_parameters/GLONASS_L1_L2_CA.h:129); almanac data the receiver provides.  With it installed,
+     *  set_local_code() applies the FDMA offset of is_fdma() (:276-293) for "1G" / "2G" signals. */
+    void set_glonass_channel_map(const std::map<uint32_t, int32_t>& prn_to_channel) { d_glonass_prn = prn_to_channel; }
+
     /*! pcps_acquisition::set_local_code (:239-274): code = d_consumed_samples complex (fft_size/2 with bit transition) */
     void set_local_code(std::complex<float>* code)
     {
         std::lock_guard<std::mutex> lock(d_setlock);
+        // reset the intermediate frequency, then the FDMA check (:242-247): DFRQ1_GLO = 562500 Hz, DFRQ2_GLO = 437500 Hz per channel
+        d_old_freq = 0;
+        if (d_gnss_synchro != nullptr && d_gnss_synchro->Signal[1] == 'G' && (d_gnss_synchro->Signal[0] == '1' || d_gnss_synchro->Signal[0] == '2'))
+            {
+                const auto it = d_glonass_prn.find(d_gnss_synchro->PRN);
+                if (it != d_glonass_prn.end()) d_old_freq += static_cast<int64_t>(d_gnss_synchro->Signal[0] == '1' ? 562500 : 437500) * it->second;
+            }
+        if (d_acq != nullptr) d_status = gc_acq_set_frequency_offset(d_acq, d_old_freq);
         const size_t n = acq_parameters.bit_transition_flag ? d_fft_size / 2 : d_consumed_samples;
         d_code.assign(code, code + n);
         if (d_acq != nullptr) d_status = gc_acq_set_local_code(d_acq, 0, reinterpret_cast<const float*>(d_code.data()));
@@ -488,6 +503,8 @@ private:
     }
 
     Acq_Conf acq_parameters;
+    int64_t d_old_freq = 0;
+    std::map<uint32_t, int32_t> d_glonass_prn;
     bool d_dump = false;
     uint32_t d_dump_channel = 0U;
     int64_t d_dump_number = 0LL;

@@ -4,6 +4,7 @@
 // Same outputs as the reference generators
 //   gps_l1_ca_code_gen_float / _complex_sampled   (src/algorithms/libs/gps_sdr_signal_processing.cc:119-196)
 //   beidou_b1i_code_gen_float / _complex_sampled   (src/algorithms/libs/beidou_b1i_signal_processing.cc:115-191)
+//   glonass_l1_ca_code_gen_complex / _complex_sampled (src/algorithms/libs/glonass_l1_signal_processing.cc:37-153; L2 C/A is the same code)
 //   galileo_e1_code_gen_sinboc11_float / _complex_sampled (src/algorithms/libs/galileo_e1_signal_processing.cc:108-255)
 //   resampler()                                    (src/algorithms/libs/gnss_signal_processing.cc:161-182)
 // written from the signal ICDs (IS-GPS-200 G1/G2 registers and G2 delays, BDS-SIS-ICD-B1I
@@ -90,6 +91,21 @@ bool bds_b1i_chips(int8_t* out, int prn, unsigned chip_shift)
 }
 
 inline int32_t aux_ceil(float x) { return static_cast<int32_t>(static_cast<int64_t>(x + 1)); }
+
+// ---- GLONASS L1 / L2 C/A (GLONASS ICD 5.1, 3.3.2.2): one 511-chip m-sequence for every satellite, generator
+// 1 + x^5 + x^9, all stages set at start, output from the 7th stage (glonass_l1_signal_processing.cc:37-97) ----
+void glonass_ca_chips(int8_t* out, unsigned chip_shift)
+{
+    uint8_t g[511];
+    unsigned r = 0x1ff;  // bit k = stage 9-k: bit 0 leaves first
+    for (int i = 0; i < 511; i++)
+        {
+            g[i] = (r >> 2) & 1;                      // 7th stage
+            const unsigned fb = ((r >> 4) ^ r) & 1;   // stages 5 and 9
+            r = (r >> 1) | (fb << 8);
+        }
+    for (int i = 0; i < 511; i++) out[i] = g[(i + chip_shift) % 511] ? 1 : -1;
+}
 
 // chips -> samples with the reference's float32 digitising rule (gps_sdr_signal_processing.cc:163-190)
 int sample_chips(float* dest_complex, const int8_t* chips, int code_len, int code_freq, int fs)
@@ -198,6 +214,25 @@ gc_status gc_gps_l1_ca_code_gen_complex_sampled(float* dest, uint32_t prn, int32
     int8_t c[1023];
     GC_REQUIRE(gps_ca_chips(c, (int)prn, chip_shift), "gc_gps_l1_ca_code_gen_complex_sampled: PRN %u not supported", prn);
     int n = sample_chips(dest, c, 1023, 1023000, fs);
+    if (n_samples) *n_samples = n;
+    return GC_OK;
+}
+
+gc_status gc_glonass_l1_ca_code_gen_float(float* dest, uint32_t chip_shift)
+{
+    GC_REQUIRE(dest, "gc_glonass_l1_ca_code_gen_float: dest is NULL");
+    int8_t c[511];
+    glonass_ca_chips(c, chip_shift);
+    for (int i = 0; i < 511; i++) dest[i] = static_cast<float>(c[i]);
+    return GC_OK;
+}
+
+gc_status gc_glonass_l1_ca_code_gen_complex_sampled(float* dest, int32_t fs, uint32_t chip_shift, int32_t* n_samples)
+{
+    GC_REQUIRE(dest && fs > 0, "gc_glonass_l1_ca_code_gen_complex_sampled: bad argument");
+    int8_t c[511];
+    glonass_ca_chips(c, chip_shift);
+    int n = sample_chips(dest, c, 511, 511000, fs);
     if (n_samples) *n_samples = n;
     return GC_OK;
 }

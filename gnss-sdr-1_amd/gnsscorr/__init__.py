@@ -176,6 +176,8 @@ API = {
     "gc_trk_loop_run": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_gps_l1_ca_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
     "gc_gps_l1_ca_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "gc_glonass_l1_ca_code_gen_float": (C.c_int, [_fp, C.c_uint32]),
+    "gc_glonass_l1_ca_code_gen_complex_sampled": (C.c_int, [_fp, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
     "gc_beidou_b1i_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
     "gc_beidou_b1i_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
     "gc_galileo_e1_code_gen_sinboc11_float": (C.c_int, [_fp, C.c_char_p, C.c_uint32]),
@@ -270,6 +272,19 @@ def gps_l1_ca_code_gen_complex_sampled(prn, fs, chip_shift=0):
     d = np.zeros(int(fs // 1000) + 8, np.complex64)
     n = C.c_int32()
     _check(load_library().gc_gps_l1_ca_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(_fp), prn, fs, chip_shift, C.byref(n)))
+    return d[:n.value].copy()
+
+
+def glonass_l1_ca_code_gen_float(chip_shift=0):
+    d = np.zeros(511, np.float32)
+    _check(load_library().gc_glonass_l1_ca_code_gen_float(_f32p(d), chip_shift))
+    return d
+
+
+def glonass_l1_ca_code_gen_complex_sampled(fs, chip_shift=0):
+    d = np.zeros(int(fs // 1000) + 8, np.complex64)
+    n = C.c_int32()
+    _check(load_library().gc_glonass_l1_ca_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(_fp), fs, chip_shift, C.byref(n)))
     return d[:n.value].copy()
 
 

@@ -336,6 +336,11 @@ gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_rec
 gc_status gc_gps_l1_ca_code_gen_float(float* dest, int32_t prn, uint32_t chip_shift);
 /* gps_l1_ca_code_gen_complex_sampled (…:151-196): (int)(fs/1000) complex samples; *n_samples (optional) = count */
 gc_status gc_gps_l1_ca_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift, int32_t* n_samples);
+/* glonass_l1_ca_code_gen_complex / _complex_sampled (src/algorithms/libs/glonass_l1_signal_processing.cc:37-153;
+ * glonass_l2_signal_processing.cc is the same sequence): 511 chips, one code for every satellite (FDMA).  The float
+ * form holds the real parts (the reference's chips are (+-1, 0)); sampled: (int)(fs/1000) complex samples. */
+gc_status gc_glonass_l1_ca_code_gen_float(float* dest, uint32_t chip_shift);
+gc_status gc_glonass_l1_ca_code_gen_complex_sampled(float* dest, int32_t fs, uint32_t chip_shift, int32_t* n_samples);
 /* beidou_b1i_code_gen_float / _complex_sampled (src/algorithms/libs/beidou_b1i_signal_processing.cc:115-191): 2046 chips */
 gc_status gc_beidou_b1i_code_gen_float(float* dest, int32_t prn, uint32_t chip_shift);
 gc_status gc_beidou_b1i_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift, int32_t* n_samples);

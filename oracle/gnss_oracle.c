@@ -400,6 +400,40 @@ int32_t orc_gps_l1_ca_code_sampled(float* dest, uint32_t prn, int32_t fs, uint32
     return sample_code(dest, chips, 1023, 1023000, fs);
 }
 
+void orc_glonass_l1_ca_code(int32_t* dest, uint32_t chip_shift)
+{
+    /* glonass_l1_signal_processing.cc:37-97: 9-stage register, all ones, output stage index 2, feedback 4 ^ 0 */
+    enum { CL = 511 };
+    unsigned char G1[CL], reg[9];
+    for (int i = 0; i < 9; i++) reg[i] = 1;
+    for (int i = 0; i < CL; i++)
+        {
+            G1[i] = reg[2];
+            unsigned char fb = reg[4] ^ reg[0];
+            for (int k = 0; k < 8; k++) reg[k] = reg[k + 1];
+            reg[8] = fb;
+        }
+    for (uint32_t i = 0; i < CL; i++) dest[i] = G1[(i + chip_shift) % CL] ? 1 : -1;
+}
+
+int32_t orc_glonass_l1_ca_code_sampled(float* dest, int32_t fs, uint32_t chip_shift)
+{
+    /* glonass_l1_signal_processing.cc:103-153 */
+    int32_t code[511];
+    const int32_t code_freq = 511000, code_len = 511;
+    const int32_t spc = (int32_t)((double)fs / (double)(code_freq / code_len));
+    const float ts = 1.0 / (float)fs, tc = 1.0 / (float)code_freq;
+    orc_glonass_l1_ca_code(code, chip_shift);
+    for (int32_t i = 0; i < spc; i++)
+        {
+            float aux = (ts * (i + 1)) / tc;
+            int32_t k = aux_ceil(aux) - 1;
+            dest[2 * i] = (float)((i == spc - 1) ? code[code_len - 1] : code[k]);
+            dest[2 * i + 1] = 0.0f;
+        }
+    return spc;
+}
+
 void orc_beidou_b1i_code(int32_t* dest, int32_t prn, uint32_t chip_shift)
 {
     /* beidou_b1i_signal_processing.cc:37-112 */

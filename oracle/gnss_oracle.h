@@ -109,6 +109,9 @@ void orc_gps_l1_ca_code(int32_t* dest /*1023*/, int32_t prn, uint32_t chip_shift
  * returns samples per code */
 int32_t orc_gps_l1_ca_code_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift);
 /* beidou_b1i_code_gen_int (algorithms/libs/beidou_b1i_signal_processing.cc:37-112) */
+/* glonass_l1_ca_code_gen_complex / _complex_sampled (algorithms/libs/glonass_l1_signal_processing.cc:37-153) */
+void orc_glonass_l1_ca_code(int32_t* dest /*511*/, uint32_t chip_shift);
+int32_t orc_glonass_l1_ca_code_sampled(float* dest, int32_t fs, uint32_t chip_shift);
 void orc_beidou_b1i_code(int32_t* dest /*2046*/, int32_t prn, uint32_t chip_shift);
 int32_t orc_beidou_b1i_code_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift);
 /* resampler() (algorithms/libs/gnss_signal_processing.cc:161-182) */

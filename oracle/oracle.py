@@ -94,6 +94,9 @@ class Oracle:
         L.orc_gps_l1_ca_code.argtypes = [c_int32_p, C.c_int32, C.c_uint32]
         L.orc_gps_l1_ca_code_sampled.argtypes = [c_float_p, C.c_uint32, C.c_int32, C.c_uint32]
         L.orc_gps_l1_ca_code_sampled.restype = C.c_int32
+        L.orc_glonass_l1_ca_code.argtypes = [c_int32_p, C.c_uint32]
+        L.orc_glonass_l1_ca_code_sampled.argtypes = [c_float_p, C.c_int32, C.c_uint32]
+        L.orc_glonass_l1_ca_code_sampled.restype = C.c_int32
         L.orc_beidou_b1i_code.argtypes = [c_int32_p, C.c_int32, C.c_uint32]
         L.orc_beidou_b1i_code_sampled.argtypes = [c_float_p, C.c_uint32, C.c_int32, C.c_uint32]
         L.orc_beidou_b1i_code_sampled.restype = C.c_int32
@@ -193,6 +196,16 @@ class Oracle:
     def gps_l1_ca_code_sampled(self, prn, fs, chip_shift=0):
         d = np.zeros(int(fs / 1000) + 8, np.complex64)
         n = self.lib.orc_gps_l1_ca_code_sampled(d.view(np.float32).ctypes.data_as(c_float_p), prn, fs, chip_shift)
+        return d[:n].copy()
+
+    def glonass_l1_ca_code(self, chip_shift=0):
+        d = np.zeros(511, np.int32)
+        self.lib.orc_glonass_l1_ca_code(d.ctypes.data_as(c_int32_p), chip_shift)
+        return d
+
+    def glonass_l1_ca_code_sampled(self, fs, chip_shift=0):
+        d = np.zeros(int(fs / 1000) + 8, np.complex64)
+        n = self.lib.orc_glonass_l1_ca_code_sampled(d.view(np.float32).ctypes.data_as(c_float_p), fs, chip_shift)
         return d[:n].copy()
 
     def beidou_b1i_code(self, prn, chip_shift=0):
@@ -312,6 +325,9 @@ class Ref:
         L.ref_index_max_generic.restype = C.c_uint
         L.ref_gps_l1_ca_code_gen_int.argtypes = [c_int32_p, C.c_int32, C.c_uint32]
         L.ref_gps_l1_ca_code_gen_complex_sampled.argtypes = [c_float_p, C.c_uint32, C.c_int32, C.c_uint32]
+        Gl = self.glo = C.CDLL(os.path.join(_HERE, "_ref", "libref_glo.so"))
+        Gl.ref_glonass_l1_ca_code_gen_complex.argtypes = [c_float_p, C.c_uint32]
+        Gl.ref_glonass_l1_ca_code_gen_complex_sampled.argtypes = [c_float_p, C.c_int32, C.c_uint32]
         B = self.bds = C.CDLL(os.path.join(_HERE, "_ref", "libref_bds.so"))
         B.ref_beidou_b1i_code_gen_int.argtypes = [c_int32_p, C.c_int32, C.c_uint32]
         B.ref_beidou_b1i_code_gen_complex_sampled.argtypes = [c_float_p, C.c_uint32, C.c_int32, C.c_uint32]
@@ -373,6 +389,16 @@ class Ref:
         d = np.zeros(n + 8, np.complex64)
         self.lib.ref_gps_l1_ca_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(c_float_p), prn, fs, chip_shift)
         return d[:n].copy()
+
+    def glonass_l1_ca_code(self, chip_shift=0):
+        d = np.zeros(511, np.complex64)
+        self.glo.ref_glonass_l1_ca_code_gen_complex(d.view(np.float32).ctypes.data_as(c_float_p), chip_shift)
+        return d
+
+    def glonass_l1_ca_code_sampled(self, fs, chip_shift=0):
+        d = np.zeros(int(fs / 1000) + 8, np.complex64)
+        self.glo.ref_glonass_l1_ca_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(c_float_p), fs, chip_shift)
+        return d[:int(fs / 1000)].copy()
 
     def beidou_b1i_code(self, prn, chip_shift=0):
         d = np.zeros(2046, np.int32)

@@ -1,7 +1,7 @@
 /*
  * ref_driver_codes.cc -- C-linkage callers for the reference's PRN generators
- * (test infrastructure).  gps_sdr_signal_processing.cc and
- * beidou_b1i_signal_processing.cc are compiled from /root/reference where they
+ * (test infrastructure).  gps_sdr_signal_processing.cc,
+ * beidou_b1i_signal_processing.cc and glonass_l1_signal_processing.cc are compiled from /root/reference where they
  * lie (oracle/Makefile target `ref`); this file only gives them C names.
  */
 #ifdef REF_BDS
@@ -9,6 +9,9 @@
 #endif
 #ifdef REF_GPS
 #include "gps_sdr_signal_processing.h"
+#endif
+#ifdef REF_GLO
+#include "glonass_l1_signal_processing.h"
 #endif
 #include <complex>
 #include <cstdint>
@@ -22,6 +25,16 @@ void ref_gps_l1_ca_code_gen_int(int32_t* dest, int32_t prn, uint32_t chip_shift)
 void ref_gps_l1_ca_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift)
 {
     gps_l1_ca_code_gen_complex_sampled(reinterpret_cast<std::complex<float>*>(dest), prn, fs, chip_shift);
+}
+#endif
+#ifdef REF_GLO
+void ref_glonass_l1_ca_code_gen_complex(float* dest, uint32_t chip_shift)
+{
+    glonass_l1_ca_code_gen_complex(reinterpret_cast<std::complex<float>*>(dest), chip_shift);
+}
+void ref_glonass_l1_ca_code_gen_complex_sampled(float* dest, int32_t fs, uint32_t chip_shift)
+{
+    glonass_l1_ca_code_gen_complex_sampled(reinterpret_cast<std::complex<float>*>(dest), fs, chip_shift);
 }
 #endif
 #ifdef REF_BDS

@@ -115,7 +115,11 @@ def main():
     codes["gps_chips_shift7"] = ref.gps_l1_ca_code(5, 7).astype(np.int8)
     codes["bds_prn"] = np.arange(1, 34, dtype=np.int32)
     codes["bds_chips"] = np.stack([ref.beidou_b1i_code(int(p)) for p in codes["bds_prn"]]).astype(np.int8)
+    codes["glo_chips"] = ref.glonass_l1_ca_code().real.astype(np.int8)
+    codes["glo_chips_shift100"] = ref.glonass_l1_ca_code(100).real.astype(np.int8)
+    assert np.all(ref.glonass_l1_ca_code().imag == 0)
     for fs in (4000000, 25000000, 2048000):
+        codes["glo_sampled_fs%d" % fs] = ref.glonass_l1_ca_code_sampled(fs).real.astype(np.int8)
         codes["gps_sampled_fs%d_prn1" % fs] = ref.gps_l1_ca_code_sampled(1, fs).real.astype(np.int8)
         codes["gps_sampled_fs%d_prn19" % fs] = ref.gps_l1_ca_code_sampled(19, fs).real.astype(np.int8)
         codes["bds_sampled_fs%d_prn6" % fs] = ref.beidou_b1i_code_sampled(6, fs).real.astype(np.int8)

@@ -36,6 +36,20 @@ def test_beidou_b1i_chips_and_sampled_codes_match_reference():
         gnsscorr.beidou_b1i_code_gen_float(0)
 
 
+def test_glonass_l1_ca_chips_and_sampled_codes_match_reference():
+    """One 511-chip m-sequence for every GLONASS satellite (FDMA): glonass_l1_signal_processing.cc compiled into oracle/_ref."""
+    import gnsscorr
+    z = np.load(os.path.join(G, "ref_codes.npz"))
+    chips = gnsscorr.glonass_l1_ca_code_gen_float()
+    assert np.array_equal(chips, z["glo_chips"].astype(np.float32))
+    assert np.array_equal(gnsscorr.glonass_l1_ca_code_gen_float(100), z["glo_chips_shift100"].astype(np.float32))
+    assert int(chips.sum()) == 1  # maximal-length sequence: 256 ones, 255 zeros
+    for fs in (4000000, 25000000, 2048000):
+        got = gnsscorr.glonass_l1_ca_code_gen_complex_sampled(fs)
+        assert got.size == fs // 1000 and np.all(got.imag == 0)
+        assert np.array_equal(got.real, z["glo_sampled_fs%d" % fs].astype(np.float32))
+
+
 def test_galileo_e1_generators(oracle):
     import gnsscorr
     z = np.load(os.path.join(G, "galileo_e1_codes.npz"))

@@ -49,7 +49,10 @@ def test_prn_generators_match_compiled_reference(oracle):
     assert np.array_equal(oracle.gps_l1_ca_code(5, 7), z["gps_chips_shift7"])
     for k, prn in enumerate(z["bds_prn"]):
         assert np.array_equal(oracle.beidou_b1i_code(int(prn)), z["bds_chips"][k])
+    assert np.array_equal(oracle.glonass_l1_ca_code(), z["glo_chips"])
+    assert np.array_equal(oracle.glonass_l1_ca_code(100), z["glo_chips_shift100"])
     for fs in (4000000, 25000000, 2048000):
+        assert np.array_equal(oracle.glonass_l1_ca_code_sampled(fs).real, z["glo_sampled_fs%d" % fs])
         assert np.array_equal(oracle.gps_l1_ca_code_sampled(1, fs).real, z["gps_sampled_fs%d_prn1" % fs])
         assert np.array_equal(oracle.gps_l1_ca_code_sampled(19, fs).real, z["gps_sampled_fs%d_prn19" % fs])
         assert np.array_equal(oracle.beidou_b1i_code_sampled(6, fs).real, z["bds_sampled_fs%d_prn6" % fs])

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -504,6 +505,14 @@ struct gc_correlator
     float2* h_out = nullptr;  // pinned
     float2* d_partial = nullptr;
     int partial_slices = 0;
+    // zero-copy path: the window is copied into page-locked, device-mapped host memory and the kernel reads it (and the
+    // descriptor) over PCIe and writes the result back the same way -- one launch and one synchronisation per call
+    // instead of three copies around the launch
+    bool zero_copy = true;
+    char* h_sig = nullptr;            // pinned, mapped
+    const void* dv_sig = nullptr;     // device view of h_sig
+    Staging* dv_stage = nullptr;      // device view of h_stage
+    float2* dv_out = nullptr;         // device view of h_out
 };
 
 static void correlator_release(gc_correlator* c)
@@ -515,6 +524,11 @@ static void correlator_release(gc_correlator* c)
     (void)hipFree(c->d_partial);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_sig) (void)hipHostFree(c->h_sig);
+    c->h_sig = nullptr;
+    c->dv_sig = nullptr;
+    c->dv_stage = nullptr;
+    c->dv_out = nullptr;
     c->d_sig = nullptr;
     c->d_code = nullptr;
     c->d_stage = nullptr;
@@ -569,26 +583,35 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
             c->code_shadow.assign(c->local_code_in, c->local_code_in + LF);
             GC_HIP(hipMemcpyAsync(c->d_code, c->code_shadow.data(), sizeof(float) * LF, hipMemcpyHostToDevice, st));
         }
-    if (N > 0) GC_HIP(hipMemcpyAsync(c->d_sig, c->sig_in, (sc16 ? sizeof(short2) : sizeof(float2)) * (size_t)N, hipMemcpyHostToDevice, st));
+    const size_t sig_bytes = (sc16 ? sizeof(short2) : sizeof(float2)) * (size_t)N;
+    const bool zc = c->zero_copy;
+    if (N > 0)
+        {
+            if (zc)
+                std::memcpy(c->h_sig, c->sig_in, sig_bytes);
+            else
+                GC_HIP(hipMemcpyAsync(c->d_sig, c->sig_in, sig_bytes, hipMemcpyHostToDevice, st));
+        }
     gc_correlator::Staging* s = c->h_stage;
     std::memset(&s->chan, 0, sizeof s->chan);
-    s->chan.iq = c->d_sig;
+    s->chan.iq = zc ? c->dv_sig : c->d_sig;
     s->chan.n_iq = (unsigned long long)N;
     s->chan.code = c->d_code;
     s->chan.code_len = L;
     for (int t = 0; t < c->n_corr; t++) s->chan.shifts[t] = c->shifts_chips[t];
     gc_epoch_params_fill(&s->params, 0, rem_carr, phase_step, phase_rate_step, rem_code, code_step, code_rate_step, N);
-    GC_HIP(hipMemcpyAsync(c->d_stage, s, sizeof *s, hipMemcpyHostToDevice, st));
+    if (!zc) GC_HIP(hipMemcpyAsync(c->d_stage, s, sizeof *s, hipMemcpyHostToDevice, st));
     // one epoch only: cut it in slices so that the launch covers many CUs
     int chunks = (N + 1 + 511) / 512;
     int n_slices = chunks / 2;
     if (n_slices < 1) n_slices = 1;
     if (n_slices > c->partial_slices) n_slices = c->partial_slices;
-    hipError_t e = trk_launch(c->n_corr, mode, sc16 ? GC_IQ_I16 : GC_IQ_F32, st, &c->d_stage->chan, &c->d_stage->params, c->d_out, c->d_partial, 1, 1,
+    gc_correlator::Staging* stage_dev = zc ? c->dv_stage : c->d_stage;
+    hipError_t e = trk_launch(c->n_corr, mode, sc16 ? GC_IQ_I16 : GC_IQ_F32, st, &stage_dev->chan, &stage_dev->params, zc ? c->dv_out : c->d_out, c->d_partial, 1, 1,
         n_slices, per_chip * (L + 64));
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
     const size_t out_bytes = (sc16 ? sizeof(short2) : sizeof(float2)) * c->n_corr;
-    GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    if (!zc) GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
     std::memcpy(c->corr_out, c->h_out, out_bytes);
     return GC_OK;
@@ -639,8 +662,28 @@ gc_status gc_correlator_init(gc_correlator* c, int max_signal_length_samples, in
     GC_HIP(hipMalloc(&c->d_stage, sizeof(gc_correlator::Staging)));
     GC_HIP(hipMalloc(&c->d_out, sizeof(float2) * GC_MAX_TAPS));
     GC_HIP(hipMalloc(&c->d_partial, sizeof(float2) * GC_MAX_TAPS * c->partial_slices));
-    GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), sizeof(gc_correlator::Staging), hipHostMallocDefault));
-    GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_out), sizeof(float2) * GC_MAX_TAPS, hipHostMallocDefault));
+    GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), sizeof(gc_correlator::Staging), hipHostMallocMapped));
+    GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_out), sizeof(float2) * GC_MAX_TAPS, hipHostMallocMapped));
+    {
+        const char* e = std::getenv("GNSSCORR_L1_COPY");  // 1: stage the window in HBM with explicit copies instead
+        c->zero_copy = !(e && e[0] == '1');
+    }
+    if (c->zero_copy)
+        {
+            void* dv = nullptr;
+            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sig), sizeof(float2) * ((size_t)max_signal_length_samples + 2), hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer(&dv, c->h_sig, 0);
+            c->dv_sig = dv;
+            if (e == hipSuccess) e = hipHostGetDevicePointer(&dv, c->h_stage, 0);
+            c->dv_stage = static_cast<gc_correlator::Staging*>(dv);
+            if (e == hipSuccess) e = hipHostGetDevicePointer(&dv, c->h_out, 0);
+            c->dv_out = static_cast<float2*>(dv);
+            if (e != hipSuccess)
+                {
+                    (void)hipGetLastError();
+                    c->zero_copy = false;  // the copy path needs none of these
+                }
+        }
     c->inited = true;
     return GC_OK;
 }

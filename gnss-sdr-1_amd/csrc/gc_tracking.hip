@@ -604,6 +604,11 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     // one epoch only: cut it in slices so that the launch covers many CUs
     int chunks = (N + 1 + 511) / 512;
     int n_slices = chunks / 2;
+    static const int one_wg_max = [] {
+        const char* e = std::getenv("GNSSCORR_L1_ONE_WG_MAX");  // tuning knob: windows up to this length run in one workgroup
+        return e ? std::atoi(e) : 2048;  // measured: beyond ~2000 samples several workgroups + the partial-sum launch win
+    }();
+    if (N <= one_wg_max) n_slices = 1;
     if (n_slices < 1) n_slices = 1;
     if (n_slices > c->partial_slices) n_slices = c->partial_slices;
     gc_correlator::Staging* stage_dev = zc ? c->dv_stage : c->d_stage;

@@ -32,11 +32,11 @@ def _run_level1(gctx, sig, code, shifts, p, high_dyn=False, rate=(0.0, 0.0)):
     return out
 
 
-@pytest.mark.parametrize("fs,n", [(4_000_000, 4000), (25_000_000, 25000)])
+@pytest.mark.parametrize("fs,n", [(2_000_000, 2000), (4_000_000, 4000), (25_000_000, 25000)])  # 2000: the single-workgroup call path
 def test_gps_l1_single_correlator_matches_oracle(gctx, oracle, fs, n):
     """cfg1/cfg2 shape: GPS L1 C/A, 3 taps, one code period, drop-in class."""
     code = oracle.gps_l1_ca_code(7).astype(np.float32)
-    sig, truth = synth_stream([code], fs, 4 * n, seed=1001, cn0_db_hz=(45.0, 45.0))
+    sig, truth = synth_stream([code], fs, 4 * n, seed=1001, cn0_db_hz=(48.0, 48.0) if n < 4000 else (45.0, 45.0))
     shifts = np.array([-0.5, 0.0, 0.5], np.float32)
     for p in open_loop_params(truth[0], fs, 1023, n, 3):
         ref = oracle.multicorrelator(sig[p["sample_offset"]:], code, shifts, p["rem_carr"], p["phase_step"],

@@ -186,6 +186,8 @@ def main():
     my_channels = sharding.weak_shard(N_CHANNELS, world, rank)
     streams, params, truths, codes = [], [], [], []
     batch = gnsscorr.TrackingBatch(ctx, N_CHANNELS, N_TAPS, CODE_LEN)
+    if os.environ.get("BENCH_SLICES"):  # tuning knob: workgroups per channel-epoch (default: the engine decides, 1 here)
+        batch.set_slices(int(os.environ["BENCH_SLICES"]))
     for ch, gid in enumerate(my_channels):
         prn = gid % 32 + 1
         code = gps_ca_code(prn)

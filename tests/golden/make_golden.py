@@ -17,7 +17,7 @@ What is produced, and where each expected value comes from:
                       int8: ICD data (Galileo OS SIS ICD, Annex C) read from the hex strings of
                       src/core/system_parameters/Galileo_E1.h and converted with the bit rule of
                       hex_to_binary_converter (gnss_signal_processing.cc:58-158: bit 1 -> -1).
-  kat_*.dat           the IQ captures the reference's own acquisition tests read
+  kat_*.dat / .bin    the IQ captures the reference's own acquisition / tracking tests read
                       (src/tests/signal_samples/), data files, copied byte for byte.
   kat_expected.json   the gates of those tests (gps_l1_ca_pcps_acquisition_test.cc:281-356,
                       galileo_e1_pcps_ambiguous_acquisition_test.cc:293-358) plus what the
@@ -190,6 +190,28 @@ def main():
             source="src/tests/unit-tests/signal-processing-blocks/acquisition/galileo_e1_pcps_ambiguous_acquisition_test.cc:293-358"),
         oracle=dict(indext=int(r.indext), doppler=int(r.doppler), test_statistics=float(r.test_statistics), mag=float(r.mag),
             input_power=float(r.input_power)))
+    # GLONASS L1 C/A: the real NT1065 capture the reference's GLONASS tracking tests read, with the acquisition
+    # hand-over those tests hard-code (Acq_delay_samples = 1343, Acq_doppler_hz = -2750 for PRN 11 = frequency channel 0,
+    # glonass_l1_ca_dll_pll_tracking_test.cc:134-167); the capture also holds strong satellites on other FDMA channels
+    shutil.copyfile(os.path.join(REF, "src/tests/signal_samples/NT1065_GLONASS_L1_20160831_fs6625e6_if0e3_4ms.bin"),
+        os.path.join(HERE, "kat_glonass_l1_nt1065_fs6625e6_4ms.bin"))
+    os.chmod(os.path.join(HERE, "kat_glonass_l1_nt1065_fs6625e6_4ms.bin"), 0o644)
+    fs = 6625000
+    x = np.fromfile(os.path.join(HERE, "kat_glonass_l1_nt1065_fs6625e6_4ms.bin"), np.complex64)
+    glo = {}
+    for k_channel in (0, -3, 4):
+        p = orc.pcps(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=6625.0,
+            samples_per_chip=13, doppler_max=10000, doppler_step=250)
+        p.set_local_code(orc.glonass_l1_ca_code_sampled(fs))
+        p.set_frequency_offset(562500 * k_channel)
+        r = p.core(x)
+        glo[str(k_channel)] = dict(indext=int(r.indext), doppler=int(r.doppler), test_statistics=float(r.test_statistics), mag=float(r.mag),
+            input_power=float(r.input_power))
+    kat["glonass_l1_ca"] = dict(file="kat_glonass_l1_nt1065_fs6625e6_4ms.bin", fs=fs, prn=11, frequency_channel=0, dfrq1_glo_hz=562500,
+        doppler_max=10000, doppler_step=250, sampled_ms=1,
+        reference_test=dict(expected_delay_samples=1343, expected_doppler_hz=-2750, max_delay_error_chips=0.5, max_doppler_error_hz=250,
+            source="src/tests/unit-tests/signal-processing-blocks/tracking/glonass_l1_ca_dll_pll_tracking_test.cc:134-167 (acquisition hand-over the test hard-codes)"),
+        oracle_by_frequency_channel=glo)
     json.dump(kat, open(os.path.join(HERE, "kat_expected.json"), "w"), indent=1)
 
     # ---- oracle-generated E/P/L regression vectors (parity unpinned) ----

@@ -268,3 +268,35 @@ def test_frequency_offset_glonass_fdma(gctx, oracle):
     _check(r, q)
     assert r.indext == delay and abs(r.doppler_hz - doppler) <= 250 and r.test_statistics > 3 * r0.test_statistics  # 1 ms: the peak is one bin wide
     acq.close()
+
+
+def test_glonass_l1_real_capture(gctx, oracle):
+    """Real GLONASS L1 data (the capture of the reference's GLONASS tracking tests): the engine with its own GLONASS
+    replica generator and the FDMA offset finds what the oracle finds, cell for cell, on three frequency channels, and
+    channel 0 is the acquisition hand-over the reference tests hard-code (1343 samples, -2750 Hz)."""
+    import gnsscorr
+    k, x = _kat("glonass_l1_ca")
+    fs = k["fs"]
+    c = dict(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=6625.0,
+        samples_per_chip=13, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+    code = gnsscorr.glonass_l1_ca_code_gen_complex_sampled(fs)
+    assert np.array_equal(code, oracle.glonass_l1_ca_code_sampled(fs))
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, **c)
+    assert (acq.fft_size, acq.num_doppler_bins) == (6625, 80)  # 6625 = 5^3 * 53: a prime radix in the row FFT
+    acq.set_local_code(0, code)
+    for kc, want in k["oracle_by_frequency_channel"].items():
+        acq.reset()
+        acq.set_frequency_offset(k["dfrq1_glo_hz"] * int(kc))
+        r = acq.dwell(x)[0]
+        p = oracle.pcps(**c)
+        p.set_local_code(code)
+        p.set_frequency_offset(k["dfrq1_glo_hz"] * int(kc))
+        _check(r, p.core(x))
+        assert (r.indext, r.doppler_hz) == (want["indext"], want["doppler"])
+    g = k["reference_test"]
+    acq.reset()
+    acq.set_frequency_offset(0)
+    r = acq.dwell(x[6625:])[0]
+    assert abs(r.acq_delay_samples - g["expected_delay_samples"]) * 511 / 6625 < g["max_delay_error_chips"]
+    assert abs(r.acq_doppler_hz - g["expected_doppler_hz"]) <= g["max_doppler_error_hz"]
+    acq.close()

@@ -128,3 +128,30 @@ def test_complex_code_state_errors(gctx):
     b.close()
     with pytest.raises(gnsscorr.GnsscorrError):
         gnsscorr.TrackingBatch(gctx, 1, 3, 8184).set_complex_codes(True)  # would not fit the LDS window
+
+
+def test_glonass_real_capture_through_the_complex_chip_correlator(gctx, oracle):
+    """The reference's GLONASS trackers hold a Cpu_Multicorrelator with the complex GLONASS replica
+    (glonass_l1_ca_dll_pll_tracking_cc.cc); here its image correlates the real NT1065 capture at the hand-over the
+    reference's test uses (delay 1343 samples, Doppler -2750 Hz): prompt on the peak, early / late half a chip down."""
+    import json
+    import os
+    import gnsscorr
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    k = json.load(open(os.path.join(G, "kat_expected.json")))["glonass_l1_ca"]
+    x = np.fromfile(os.path.join(G, k["file"]), np.complex64)
+    fs, n = k["fs"], 6625
+    code = gnsscorr.glonass_l1_ca_code_gen_float().astype(np.complex64)  # glonass_l1_ca_code_gen_complex: (+-1, 0)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    delay = k["oracle_by_frequency_channel"]["0"]["indext"]
+    dopp = float(k["reference_test"]["expected_doppler_hz"])
+    step = np.float32(511.0 / n)
+    mags = []
+    for ms in range(3):
+        p = dict(sample_offset=delay + ms * n, rem_carr=np.float32(0.0), phase_step=np.float32(2 * np.pi * dopp / fs), rem_code=np.float32(0.0), code_step=step)
+        ref = oracle.multicorrelator_cc(x[p["sample_offset"]:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
+        got = _level1(gctx, x, code, shifts, p, n)
+        assert rel_err(got, ref, 1) <= TOL
+        mags.append(np.abs(got))
+    m = np.mean(mags, axis=0)
+    assert m[1] > 1.3 * m[0] and m[1] > 1.3 * m[2] and m[1] > 800.0  # a correlation peak (sums of pure noise are ~ sqrt(6625) * 2.1 = 170)

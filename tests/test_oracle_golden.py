@@ -144,6 +144,37 @@ def test_pcps_galileo_e1_known_answer(oracle):
     assert r.test_statistics > k["threshold"]
 
 
+def test_pcps_glonass_l1_real_capture(oracle):
+    """The NT1065 GLONASS L1 capture of the reference's GLONASS tracking tests: a PCPS search with the GLONASS C/A
+    replica on frequency channel 0 lands on the acquisition hand-over those tests hard-code (delay 1343 samples,
+    Doppler -2750 Hz for PRN 11; glonass_l1_ca_dll_pll_tracking_test.cc:134-167).  Satellites on other FDMA channels
+    need d_old_freq = DFRQ1_GLO * k (pcps_acquisition.cc:276-293)."""
+    k, x = _kat("glonass_l1_ca")
+    fs = k["fs"]
+    conf = dict(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=6625.0,
+        samples_per_chip=13, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+    code = oracle.glonass_l1_ca_code_sampled(fs)
+    assert code.size == 6625 and x.size >= 4 * 6625 - 1
+    g = k["reference_test"]
+    for ms in range(3):  # the satellite is there in every millisecond of the capture
+        p = oracle.pcps(**conf)
+        p.set_local_code(code)
+        r = p.core(x[ms * 6625:])
+        assert abs(r.acq_delay_samples - g["expected_delay_samples"]) * 511 / 6625 < g["max_delay_error_chips"]
+        assert abs(r.acq_doppler_hz - g["expected_doppler_hz"]) <= g["max_doppler_error_hz"]
+    for kc, want in k["oracle_by_frequency_channel"].items():
+        p = oracle.pcps(**conf)
+        p.set_local_code(code)
+        p.set_frequency_offset(k["dfrq1_glo_hz"] * int(kc))
+        r = p.core(x)
+        assert (r.indext, r.doppler) == (want["indext"], want["doppler"])
+        assert r.test_statistics == pytest.approx(want["test_statistics"], rel=1e-6)
+    # without the FDMA offset the channel -3 satellite is not found where it is
+    p = oracle.pcps(**conf)
+    p.set_local_code(code)
+    assert p.core(x).indext != k["oracle_by_frequency_channel"]["-3"]["indext"]
+
+
 def test_pcps_second_peak_and_dwells(oracle):
     """Two non-coherent dwells switch the statistic to first/second peak (pcps_acquisition.cc:152-159)
     and accumulate |.|^2 (:737-738)."""

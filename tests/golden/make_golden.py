@@ -212,6 +212,27 @@ def main():
         reference_test=dict(expected_delay_samples=1343, expected_doppler_hz=-2750, max_delay_error_chips=0.5, max_doppler_error_hz=250,
             source="src/tests/unit-tests/signal-processing-blocks/tracking/glonass_l1_ca_dll_pll_tracking_test.cc:134-167 (acquisition hand-over the test hard-codes)"),
         oracle_by_frequency_channel=glo)
+    # Galileo E1, real signal: the GSoC 2012 CTTC roof capture (4 Msps, 4 ms) with the MATLAB analysis the reference ships
+    # beside it (GSoC_CTTC_capture_2012_07_26_4Msps_4ms_analysis.txt: PRN 11 at 13873 samples / 9500 Hz, PRN 12 at 10583 / 7250 Hz
+    # on a 125 Hz grid; that 2012 listing prints the Doppler with the opposite sign of today's pcps_acquisition convention,
+    # which the two synthetic KATs above pin)
+    shutil.copyfile(os.path.join(REF, "src/tests/signal_samples/GSoC_CTTC_capture_2012_07_26_4Msps_4ms.dat"),
+        os.path.join(HERE, "kat_gsoc_cttc_capture_4msps_4ms.dat"))
+    os.chmod(os.path.join(HERE, "kat_gsoc_cttc_capture_4msps_4ms.dat"), 0o644)
+    fs = 4000000
+    x = np.fromfile(os.path.join(HERE, "kat_gsoc_cttc_capture_4msps_4ms.dat"), np.complex64)
+    real = {}
+    for prn in (11, 12, 19, 20):
+        p = orc.pcps(fs_in=fs, sampled_ms=4, ms_per_code=4, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=16000.0,
+            samples_per_chip=4, doppler_max=10000, doppler_step=125)
+        p.set_local_code(orc.galileo_e1_code_sampled(e1b[prn - 1], fs, cboc=False).astype(np.complex64))
+        r = p.core(x)
+        real[str(prn)] = dict(indext=int(r.indext), doppler=int(r.doppler), test_statistics=float(r.test_statistics), mag=float(r.mag),
+            input_power=float(r.input_power))
+    kat["galileo_e1_real_capture"] = dict(file="kat_gsoc_cttc_capture_4msps_4ms.dat", fs=fs, doppler_max=10000, doppler_step=125, sampled_ms=4,
+        reference_analysis={"11": dict(delay_samples=13873, abs_doppler_hz=9500), "12": dict(delay_samples=10583, abs_doppler_hz=7250),
+            "source": "src/tests/signal_samples/GSoC_CTTC_capture_2012_07_26_4Msps_4ms_analysis.txt (plot_acq_grid_gsoc.m results)"},
+        absent_prns=[19, 20], oracle_by_prn=real)
     json.dump(kat, open(os.path.join(HERE, "kat_expected.json"), "w"), indent=1)
 
     # ---- oracle-generated E/P/L regression vectors (parity unpinned) ----

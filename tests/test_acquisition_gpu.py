@@ -300,3 +300,33 @@ def test_glonass_l1_real_capture(gctx, oracle):
     assert abs(r.acq_delay_samples - g["expected_delay_samples"]) * 511 / 6625 < g["max_delay_error_chips"]
     assert abs(r.acq_doppler_hz - g["expected_doppler_hz"]) <= g["max_doppler_error_hz"]
     acq.close()
+
+
+def test_galileo_e1_real_capture_batched(gctx, oracle):
+    """Real Galileo E1 data (GSoC 2012 roof capture, with the MATLAB analysis the reference ships beside it): PRN 11 and 12
+    present, 19 and 20 absent, searched in one batched call on a 160-bin grid; every result equals the oracle's cell for
+    cell and the present satellites sit where the analysis puts them."""
+    import gnsscorr
+    k, x = _kat("galileo_e1_real_capture")
+    fs = k["fs"]
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    c = dict(fs_in=fs, sampled_ms=4, ms_per_code=4, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=16000.0,
+        samples_per_chip=4, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+    prns = [11, 12, 19, 20]
+    acq = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
+    orcs = []
+    for s_, prn in enumerate(prns):
+        code = gnsscorr.galileo_e1_code_gen_complex_sampled("1B", False, prn, fs)
+        assert np.array_equal(code.real, oracle.galileo_e1_code_sampled(e1b[prn - 1], fs, cboc=False))
+        acq.set_local_code(s_, code)
+        p = oracle.pcps(**c)
+        p.set_local_code(code)
+        orcs.append(p)
+    res = acq.dwell(x)
+    for s_, prn in enumerate(prns):
+        _check(res[s_], orcs[s_].core(x))
+    for prn, a in ((11, k["reference_analysis"]["11"]), (12, k["reference_analysis"]["12"])):
+        r = res[prns.index(prn)]
+        assert r.indext == a["delay_samples"] and abs(r.doppler_hz) == a["abs_doppler_hz"]
+    assert min(res[0].test_statistics, res[1].test_statistics) > 2.0 * max(res[2].test_statistics, res[3].test_statistics)
+    acq.close()

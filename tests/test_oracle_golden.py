@@ -175,6 +175,29 @@ def test_pcps_glonass_l1_real_capture(oracle):
     assert p.core(x).indext != k["oracle_by_frequency_channel"]["-3"]["indext"]
 
 
+def test_pcps_galileo_e1_real_capture(oracle):
+    """Real Galileo E1 signal (GSoC 2012 roof capture): the reference ships a MATLAB analysis of its acquisition grid beside
+    the file -- PRN 11 at 13873 samples / 9500 Hz and PRN 12 at 10583 samples / 7250 Hz.  Delays must match exactly and the
+    Doppler magnitudes exactly (that 2012 listing uses the opposite Doppler sign of today's pcps_acquisition)."""
+    k, x = _kat("galileo_e1_real_capture")
+    fs = k["fs"]
+    z = np.load(os.path.join(G, "galileo_e1_codes.npz"))
+    stats = {}
+    for prn in (11, 12, 19, 20):
+        p = oracle.pcps(fs_in=fs, sampled_ms=4, ms_per_code=4, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=16000.0,
+            samples_per_chip=4, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+        assert (p.fft_size, p.num_doppler_bins) == (16000, 160)
+        p.set_local_code(oracle.galileo_e1_code_sampled(z["e1b"][prn - 1], fs, cboc=False).astype(np.complex64))
+        r = p.core(x)
+        stats[prn] = r.test_statistics
+        want = k["oracle_by_prn"][str(prn)]
+        assert (r.indext, r.doppler) == (want["indext"], want["doppler"])
+        if str(prn) in k["reference_analysis"]:
+            a = k["reference_analysis"][str(prn)]
+            assert r.indext == a["delay_samples"] and abs(r.doppler) == a["abs_doppler_hz"]
+    assert min(stats[11], stats[12]) > 2.0 * max(stats[19], stats[20])
+
+
 def test_pcps_second_peak_and_dwells(oracle):
     """Two non-coherent dwells switch the statistic to first/second peak (pcps_acquisition.cc:152-159)
     and accumulate |.|^2 (:737-738)."""

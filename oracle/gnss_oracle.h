@@ -7,13 +7,18 @@
  * The product path (libgnsscorr.so, HIP) never links or loads this file.
  *
  * Pinning status (see DESIGN.md "Oracle"):
- *   - code NCO / resampler chip indices, PRN generators (GPS L1 C/A, BeiDou B1I),
- *     running-phase sincos, argmax:  PINNED against the reference's own sources
- *     compiled into oracle/_ref (oracle/Makefile target `ref`).
+ *   - code NCO / resampler chip indices (real, high-dynamics, complex-chip and
+ *     int16-chip resamplers), PRN generators (GPS L1 C/A, BeiDou B1I, GLONASS
+ *     L1 C/A), running-phase sincos, argmax:  PINNED against the reference's own
+ *     sources compiled into oracle/_ref (oracle/Makefile target `ref`).
  *   - PCPS acquisition:              PINNED by the reference's own known-answer
  *     tests (GPS_L1_CA_ID_1_Fs_4Msps_2ms.dat -> 524 samples / 1680 Hz, Galileo
- *     E1 file -> 2920 samples / -632 Hz); exact grid values (FFTW rounding) are
- *     not reproducible and are PARITY UNPINNED beyond those tests.
+ *     E1 file -> 2920 samples / -632 Hz) and by two real captures the reference
+ *     ships: the NT1065 GLONASS L1 file of its tracking tests (the search lands
+ *     on the hand-over they hard-code, 1343 samples / -2750 Hz) and the GSoC 2012
+ *     Galileo E1 file with its MATLAB analysis (PRN 11 / 12 delays exact); exact
+ *     grid values (FFTW rounding) are not reproducible and are PARITY UNPINNED
+ *     beyond those tests.
  *   - rotator + dot-product accumulate (E/P/L values): PARITY UNPINNED -- the
  *     reference kernel header needs the Mako-generated <volk_gnsssdr/volk_gnsssdr.h>
  *     which cannot be generated here, and no reference test stores E/P/L values.

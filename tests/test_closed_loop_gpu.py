@@ -173,3 +173,35 @@ def test_closed_loop_declares_loss_of_lock(gctx, oracle):
     lost = int(np.argmax(states == 0))
     assert states[lost] == 0 and 80 < lost <= 80 + 11 * (5 + 2) + 11        # ~max_lock_fail failed tests of 11 epochs each
     assert np.all(states[lost:] == 0) and np.all(rec["valid"][lost:] == 0)   # standby from then on
+
+
+def test_closed_loop_on_the_real_glonass_capture(gctx, oracle):
+    """GlonassL1CaDllPllTrackingTest.ValidationOfResults (glonass_l1_ca_dll_pll_tracking_test.cc:151-214) runs the tracking
+    block over the 4 ms NT1065 capture from the hand-over (1343 samples, -2750 Hz, PRN 11) without asserting anything; here
+    the device loop runs the same three code periods and the prompt must sit on the correlation peak in each of them."""
+    import json
+    import os
+    import gnsscorr
+    import torch
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    k = json.load(open(os.path.join(G, "kat_expected.json")))["glonass_l1_ca"]
+    x = np.fromfile(os.path.join(G, k["file"]), np.complex64)
+    g = k["reference_test"]
+    conf = dict(fs_in=float(k["fs"]), signal_carrier_freq_hz=1602.0e6, code_chip_rate_hz=0.511e6, code_period_s=0.001, carrier_lock_th=0.85,
+        code_length_chips=511, code_samples_per_chip=1, vector_length=6625, pull_in_time_s=2, veml=0, pll_filter_order=2, dll_filter_order=2,
+        enable_fll_pull_in=0, enable_fll_steady_state=0, cn0_samples=20, cn0_min=25, max_lock_fail=50, pll_bw_hz=2.0, dll_bw_hz=0.5, fll_bw_hz=10.0,
+        early_late_space_chips=0.5, very_early_late_space_chips=0.0, acq_delay_samples=float(g["expected_delay_samples"]),
+        acq_doppler_hz=float(g["expected_doppler_hz"]), acq_samplestamp_samples=0, sample_counter=0)
+    d = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 511)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.start(0, _conf(gnsscorr, **conf), gnsscorr.glonass_l1_ca_code_gen_float())
+    rec = loop.run(4)[0]
+    loop.close()
+    # the pull-in of the block skips T_prn - fmod(-1343, T_prn) = 6625 + 1343 samples (dll_pll_veml_tracking.cc:1568-1600),
+    # so two whole code periods of the 26499-sample capture are left
+    assert list(rec["valid"]) == [1, 1, 0, 0]
+    assert int(rec["sample_counter"][0]) == 6625 + 1343 + 6625 and abs(int(rec["sample_counter"][1]) - int(rec["sample_counter"][0]) - 6625) <= 1
+    mag = np.abs(rec["corr"][:2, 0::2] + 1j * rec["corr"][:2, 1::2])[:, :3]
+    assert np.all(mag[:, 1] > 1.25 * mag[:, 0]) and np.all(mag[:, 1] > 1.25 * mag[:, 2]) and np.all(mag[:, 1] > 700.0)
+    assert np.all(np.abs(rec["carrier_doppler_hz"][:2] - g["expected_doppler_hz"]) < 50.0)

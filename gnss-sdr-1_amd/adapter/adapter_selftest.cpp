@@ -42,7 +42,7 @@ static std::vector<gr_complex> read_iq(const std::string& path)
     size_t bytes = static_cast<size_t>(f.tellg());
     v.resize(bytes / sizeof(gr_complex));
     f.seekg(0);
-    f.read(reinterpret_cast<char*>(v.data()), bytes);
+    f.read(reinterpret_cast<char*>(v.data()), static_cast<std::streamsize>(v.size() * sizeof(gr_complex)));  // whole samples only
     return v;
 }
 
@@ -339,6 +339,56 @@ static void test_galileo_acquisition(const std::string& dir)
     std::printf("Galileo E1 acquisition: delay %g samples, Doppler %g Hz, statistic %g\n", gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz, blk->test_statistics());
 }
 
+static void test_glonass_acquisition(const std::string& dir)
+{
+    // real GLONASS L1 data: the NT1065 capture of glonass_l1_ca_dll_pll_tracking_test.cc, whose hard-coded hand-over is
+    // delay 1343 samples / Doppler -2750 Hz for PRN 11 (frequency channel 0); slot 2 -> channel -4 in GLONASS_PRN
+    auto x = read_iq(dir + "/kat_glonass_l1_nt1065_fs6625e6_4ms.bin");
+    EXPECT(x.size() == 26499, "capture size %zu", x.size());
+    x.resize(26500);
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "6625000");
+    config.set_property("Acquisition_1G.doppler_max", "10000");
+    config.set_property("Acquisition_1G.doppler_step", "250");
+    Gnss_Synchro gnss_synchro;
+    gnss_synchro.System = 'R';
+    gnss_synchro.Signal[0] = '1';
+    gnss_synchro.Signal[1] = 'G';
+    gnss_synchro.PRN = 11;
+    GlonassL1CaPcpsAcquisitionHip acquisition(&config, "Acquisition_1G", 1, 0);
+    EXPECT(acquisition.implementation() == "GLONASS_L1_CA_PCPS_Acquisition_HIP", "implementation name");
+    EXPECT(acquisition.vector_length() == 6625, "vector length %u", acquisition.vector_length());
+    acquisition.block()->set_glonass_channel_map({{11, 0}, {2, -4}});
+    acquisition.set_channel(0);
+    acquisition.set_gnss_synchro(&gnss_synchro);
+    acquisition.set_threshold(0.005f);
+    acquisition.set_doppler_max(10000);
+    acquisition.set_doppler_step(250);
+    acquisition.init();
+    acquisition.set_local_code();
+    acquisition.set_state(1);
+    run_flowgraph(acquisition, x, 2048);
+    auto blk = acquisition.block();
+    EXPECT(blk->last_status() == GC_OK, "engine status %d: %s", blk->last_status(), gc_last_error());
+    EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "expected ACQ SUCCESS (%zu events)", blk->events().size());
+    const long start = static_cast<long>(gnss_synchro.Acq_samplestamp_samples) - 6625;
+    const double expected_delay = static_cast<double>(((1343 - start) % 6625 + 6625) % 6625);
+    EXPECT(std::abs(expected_delay - gnss_synchro.Acq_delay_samples) <= 2.0, "delay %g (expected %g)", gnss_synchro.Acq_delay_samples, expected_delay);
+    EXPECT(std::abs(-2750.0 - gnss_synchro.Acq_doppler_hz) <= 250.0, "Doppler %g Hz", gnss_synchro.Acq_doppler_hz);
+    std::printf("GLONASS L1 C/A acquisition (real capture, PRN 11 / channel 0): delay %g samples, Doppler %g Hz, statistic %g\n", gnss_synchro.Acq_delay_samples,
+        gnss_synchro.Acq_doppler_hz, blk->test_statistics());
+    // slot 2 lives on frequency channel -4: the block installs DFRQ1_GLO * (-4) in set_local_code() and finds the satellite there
+    gnss_synchro.PRN = 2;
+    blk->clear_events();
+    acquisition.set_local_code();
+    acquisition.set_state(1);
+    run_flowgraph(acquisition, x, 2048);
+    EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "channel -4: expected ACQ SUCCESS (%zu events)", blk->events().size());
+    EXPECT(std::abs(3000.0 - gnss_synchro.Acq_doppler_hz) <= 250.0, "channel -4 Doppler %g Hz", gnss_synchro.Acq_doppler_hz);
+    std::printf("GLONASS L1 C/A acquisition (slot 2 / channel -4, FDMA offset %d Hz): delay %g samples, Doppler %g Hz, statistic %g\n", -4 * 562500,
+        gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz, blk->test_statistics());
+}
+
 static void test_beidou_sizes()
 {
     // the BeiDou adapter leaves Acq_Conf::ms_per_code at 0, so the block doubles the FFT (pcps_acquisition.cc:78-85)
@@ -390,6 +440,7 @@ int main(int argc, char** argv)
     test_gps_acquisition(argv[1], false);
     test_gps_acquisition(argv[1], true);
     test_galileo_acquisition(argv[1]);
+    test_glonass_acquisition(argv[1]);
     test_beidou_sizes();
     std::printf(g_fail ? "%d FAILURES\n" : "adapter self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

@@ -6,6 +6,7 @@
  *   GpsL1CaPcpsAcquisition           src/algorithms/acquisition/adapters/gps_l1_ca_pcps_acquisition.cc:46-358
  *   GalileoE1PcpsAmbiguousAcquisition src/algorithms/acquisition/adapters/galileo_e1_pcps_ambiguous_acquisition.cc:46-330
  *   BeidouB1iPcpsAcquisition          src/algorithms/acquisition/adapters/beidou_b1i_pcps_acquisition.cc:45-330
+ *   GlonassL1CaPcpsAcquisition        src/algorithms/acquisition/adapters/glonass_l1_ca_pcps_acquisition.cc:44-330
  * (item_type gr_complex only; `dump` / `dump_filename` / `dump_channel` write the reference's .mat
  * variables, see hip_pcps_acquisition::dump_results; the acquisition resampler and the GNU Radio
  * connect()/get_left_block() plumbing are outside this path).  Registration in a GNSS-SDR tree is one
@@ -27,7 +28,8 @@ enum class AcqSignal
 {
     GPS_L1_CA,
     GALILEO_E1,
-    BEIDOU_B1I
+    BEIDOU_B1I,
+    GLONASS_L1_CA
 };
 
 // constants of GPS_L1_CA.h:54-61, Galileo_E1.h:55-60, Beidou_B1I.h:52-56
@@ -49,6 +51,8 @@ inline AcqSignalTraits acq_traits(AcqSignal s)
             return {1.023e6, 4092.0, 1.0 / 1.023e6, 0.004, 4, "Galileo_E1_PCPS_Ambiguous_Acquisition_HIP"};
         case AcqSignal::BEIDOU_B1I:
             return {2.046e6, 2046.0, 4.8875e-07, 0.001, 1, "BEIDOU_B1I_PCPS_Acquisition_HIP"};
+        case AcqSignal::GLONASS_L1_CA:
+            return {0.511e6, 511.0, 1.9569e-06, 0.001, 1, "GLONASS_L1_CA_PCPS_Acquisition_HIP"};  // GLONASS_L1_L2_CA.h:93-97
         default:
             return {1.023e6, 1023.0, 9.7752e-07, 0.001, 1, "GPS_L1_CA_PCPS_Acquisition_HIP"};
         }
@@ -114,6 +118,19 @@ public:
                 acq_parameters_.samples_per_code = acq_parameters_.samples_per_ms * static_cast<float>(4);
                 vector_length_ = sampled_ms_ * acq_parameters_.samples_per_ms;
                 if (acq_parameters_.bit_transition_flag) vector_length_ *= 2;
+            }
+        else if (SIG == AcqSignal::GLONASS_L1_CA)
+            {
+                // glonass_l1_ca_pcps_acquisition.cc:62-113
+                sampled_ms_ = configuration_->property(role + ".coherent_integration_time_ms", 1);
+                acq_parameters_.sampled_ms = sampled_ms_;
+                acq_parameters_.ms_per_code = 1;
+                acq_parameters_.samples_per_chip = static_cast<unsigned int>(std::ceil(t.chip_period_s * static_cast<float>(acq_parameters_.fs_in)));
+                code_length_ = static_cast<unsigned int>(std::round(static_cast<double>(fs_in_) / (t.code_rate_hz / t.code_length_chips)));
+                vector_length_ = code_length_ * sampled_ms_;
+                if (acq_parameters_.bit_transition_flag) vector_length_ *= 2;
+                acq_parameters_.samples_per_ms = static_cast<float>(fs_in_) * 0.001;
+                acq_parameters_.samples_per_code = acq_parameters_.samples_per_ms * static_cast<float>(t.code_period_s * 1000.0);
             }
         else
             {
@@ -183,6 +200,8 @@ public:
             gc_gps_l1_ca_code_gen_complex_sampled(dst, gnss_synchro_->PRN, static_cast<int32_t>(fs_in_), 0, nullptr);
         else if (SIG == AcqSignal::BEIDOU_B1I)
             gc_beidou_b1i_code_gen_complex_sampled(dst, gnss_synchro_->PRN, static_cast<int32_t>(fs_in_), 0, nullptr);
+        else if (SIG == AcqSignal::GLONASS_L1_CA)
+            gc_glonass_l1_ca_code_gen_complex_sampled(dst, static_cast<int32_t>(fs_in_), 0, nullptr);  // one code for every slot (FDMA)
         else
             {
                 // galileo_e1_pcps_ambiguous_acquisition.cc:240-284: the cboc flag is looked up per channel
@@ -246,5 +265,7 @@ private:
 using GpsL1CaPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GPS_L1_CA>;
 using GalileoE1PcpsAmbiguousAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GALILEO_E1>;
 using BeidouB1iPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::BEIDOU_B1I>;
+//! the block applies the FDMA offset in set_local_code() once hip_pcps_acquisition::set_glonass_channel_map() holds the almanac
+using GlonassL1CaPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GLONASS_L1_CA>;
 
 #endif  // GNSSCORR_PCPS_ACQUISITION_ADAPTERS_H_

@@ -1028,12 +1028,15 @@ static bool factor_rows(int N2, int* fac, int* n_fac)
                     }
             if (!r)
                 {
-                    for (int p = 7; p <= 61; p += 2)
+                    // any other prime factor: the generic O(R^2) butterfly (slow for large R, but every length the
+                    // LDS can hold is transformed -- the reference's FFTW takes any length)
+                    for (int p = 7; (long)p * p <= n; p += 2)
                         if (n % p == 0)
                             {
                                 r = p;
                                 break;
                             }
+                    if (!r) r = n;  // n itself is prime
                 }
             if (!r || k >= ACQ_MAX_FACTORS) return false;
             fac[k++] = r;

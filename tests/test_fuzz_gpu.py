@@ -80,3 +80,62 @@ def test_randomised_open_loop_parity(gctx, oracle):
         fmt = ["GC_IQ_F32", "GC_IQ_F32", "GC_IQ_I16", "GC_IQ_I8"][i % 4]
         worst = max(worst, _one_batch(gctx, oracle, rng, fmt, high_dyn=(i % 5 == 4)))
     print("worst error / tolerance over %d channel-epochs: %.3f" % (n_batches * 48, worst))
+
+
+def test_randomised_acquisition_parity(gctx, oracle):
+    """PCPS engine against the oracle over random block sizes (every radix mix the planner produces, primes up to 61
+    included), zero-padded and bit-transition layouts, 1-3 dwells, both statistics, 1-3 satellites."""
+    import gnsscorr
+    n_cases = int(os.environ.get("GNSSCORR_FUZZ_ACQ_CASES", "40"))
+    rng = np.random.Generator(np.random.PCG64(77077))
+    done = unsupported = 0
+    while done < n_cases:
+        spms = int(rng.choice([200, 256, 250, 341, 400, 500, 511, 610, 1000, 1023, 1024, 1331, 2000, 2046, int(rng.integers(100, 2500))]))
+        fs = spms * 1000
+        ms_per_code = int(rng.choice([1, 1, 4]))
+        sampled_ms = int(rng.choice([1, 2, 4])) if ms_per_code == 1 else int(rng.choice([4, 8]))
+        bt = bool(rng.random() < 0.2)
+        max_dwells = 1 if bt else int(rng.integers(1, 4))
+        use_cfar = bool(rng.random() < 0.5)
+        dmax = int(rng.choice([500, 1000, 2000]))
+        dstep = int(rng.choice([125, 250, 500]))
+        n_sats = int(rng.integers(1, 4))
+        c = dict(fs_in=fs, sampled_ms=sampled_ms, ms_per_code=ms_per_code, samples_per_ms=np.float32(fs) * np.float32(0.001),
+            samples_per_code=float(spms * ms_per_code), samples_per_chip=max(1, spms // 1000 + 1), doppler_max=dmax, doppler_step=dstep,
+            max_dwells=max_dwells, bit_transition_flag=bt, use_cfar=use_cfar)
+        try:
+            acq = gnsscorr.PcpsAcquisition(gctx, n_sats, **c)
+        except gnsscorr.GnsscorrError as e:
+            # only a block whose shortest row (a large prime factor) does not fit the LDS is refused, never mis-computed
+            assert "factorisation" in str(e), e
+            unsupported += 1
+            continue
+        consumed = acq.consumed_samples
+        code_len = acq.fft_size // 2 if bt else consumed
+        n_total = consumed * max_dwells
+        x = ((rng.standard_normal(n_total) + 1j * rng.standard_normal(n_total)) * np.sqrt(0.5)).astype(np.complex64)
+        orcs = []
+        for s in range(n_sats):
+            period = np.sign(rng.standard_normal(spms * ms_per_code)).astype(np.float32)
+            code = np.tile(period, -(-code_len // period.size))[:code_len].astype(np.complex64)
+            if s == 0:  # the first satellite is in the signal
+                delay, dopp = int(rng.integers(0, period.size)), float(rng.uniform(-dmax, dmax))
+                t = np.arange(n_total)
+                x += (0.4 * np.tile(np.roll(period, delay), -(-n_total // period.size))[:n_total] * np.exp(2j * np.pi * dopp * t / fs)).astype(np.complex64)
+            acq.set_local_code(s, code)
+            p = oracle.pcps(**c)
+            p.set_local_code(code)
+            orcs.append(p)
+        for d in range(max_dwells):
+            blk = x[d * consumed:(d + 1) * consumed]
+            res = acq.dwell(blk)
+            for s in range(n_sats):
+                q = orcs[s].core(blk)
+                r = res[s]
+                assert (r.indext, r.doppler_hz, r.doppler_index) == (q.indext, q.doppler, q.doppler_index), (c, s, d)
+                assert r.mag == pytest.approx(q.mag, rel=1e-4) and r.test_statistics == pytest.approx(q.test_statistics, rel=2e-4), (c, s, d)
+        grid, ref = acq.grid(0), orcs[0].grid()
+        assert np.max(np.abs(grid - ref)) <= 1e-4 * ref.max(), c
+        acq.close()
+        done += 1
+    print("acquisition cases: %d checked, %d sizes refused" % (done, unsupported))

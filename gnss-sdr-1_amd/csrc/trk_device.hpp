@@ -262,9 +262,11 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
         int n0 = v - a, n1 = v + 1 - a;
         if (!FULL)
             {
-                // masked lanes carry zero input; keep their sample number inside the window
-                n0 = min(max(n0, 0), N - 1);
-                n1 = min(max(n1, 0), N - 1);
+                // masked lanes carry zero input; keep their sample number inside the window (an EMPTY window with an
+                // odd start still runs one all-masked chunk: sample 0 is what the LDS window was built for)
+                const int nmax = max(N - 1, 0);
+                n0 = min(max(n0, 0), nmax);
+                n1 = min(max(n1, 0), nmax);
             }
         if (HDC)
             {
@@ -310,8 +312,8 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
                             {
                                 m0 = (m0 >= N) ? m0 - N : m0;
                                 m1 = (m1 >= N) ? m1 - N : m1;
-                                m0 = min(max(m0, 0), N - 1);
-                                m1 = min(max(m1, 0), N - 1);
+                                m0 = min(max(m0, 0), max(N - 1, 0));
+                                m1 = min(max(m1, 0), max(N - 1, 0));
                             }
                         const int i0 = chip_index_hd(step, rate, (unsigned)m0, shifts[0], rem);
                         const int i1 = chip_index_hd(step, rate, (unsigned)m1, shifts[0], rem);

@@ -139,3 +139,52 @@ def test_randomised_acquisition_parity(gctx, oracle):
         acq.close()
         done += 1
     print("acquisition cases: %d checked, %d sizes refused" % (done, unsupported))
+
+
+def test_randomised_complex_and_16bit_codes(gctx, oracle):
+    """The complex-chip (Cpu_Multicorrelator) and 16-bit (Cpu_Multicorrelator_16sc) paths over random set-ups."""
+    import gnsscorr
+    import torch
+    rng = np.random.Generator(np.random.PCG64(4242))
+    for i in range(int(os.environ.get("GNSSCORR_FUZZ_BATCHES", "60")) // 2):
+        sc16 = (i % 2 == 1)
+        n_taps = int(rng.integers(1, 9))
+        L = int(rng.choice([1, 7, 511, 1023, 2046, int(rng.integers(3, 7000))]))
+        shifts = np.sort(rng.uniform(-2.0, 2.0, n_taps)).astype(np.float32)
+        n_sig, n_epochs = 12000, 32
+        raw = rng.standard_normal((n_sig, 2))
+        b = gnsscorr.TrackingBatch(gctx, 1, n_taps, L)
+        if sc16:
+            q = np.round(raw * 40).astype(np.int16)
+            code = np.stack([np.sign(rng.standard_normal(L)) * rng.integers(1, 3), rng.integers(-1, 2, L)], 1).astype(np.int16)
+            b.set_16sc(True)
+            b.set_code_16sc(0, code, shifts)
+        else:
+            q = raw.astype(np.float32)
+            code = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+            b.set_complex_codes(True)
+            b.set_code_complex(0, code, shifts)
+        d = torch.from_numpy(q).cuda()
+        b.set_input_dev(0, d.data_ptr(), n_sig)
+        recs, refs = [], []
+        for _ in range(n_epochs):
+            n = int(rng.choice([0, 1, 255, 256, 257, 512, 1000, 4000, int(rng.integers(0, 5000))]))
+            off = int(rng.integers(0, n_sig - n + 1))
+            a = [np.float32(rng.uniform(-7, 7)), np.float32(rng.uniform(-0.05, 0.05)), np.float32(rng.uniform(-2 * L, 2 * L)), np.float32(rng.uniform(0.01, 1.5))]
+            recs.append(gnsscorr.epoch_params(off, float(a[0]), float(a[1]), float(a[2]), float(a[3]), n))
+            if sc16:
+                refs.append(oracle.multicorrelator_16sc(q[off:], code, shifts, a[0], a[1], a[2], a[3], n))
+            else:
+                refs.append(oracle.multicorrelator_cc(q[off:].reshape(-1).view(np.complex64), code, shifts, a[0], a[1], a[2], a[3], n))
+        out = b.run(n_epochs, gnsscorr.epoch_params_array(recs))[0]
+        b.close()
+        for k in range(n_epochs):
+            n = recs[k].n_samples
+            if sc16:
+                ref, exact = refs[k]
+                want = ref.astype(np.int32) if np.array_equal(ref.astype(np.int32), exact) else np.clip(exact, -32768, 32767)
+                # a sample whose rotated value rounds the other way moves a sum by one chip: |re| + |im| <= 3 here
+                assert np.abs(out[k].astype(np.int32) - want).max() <= 3 * 3, (i, k, n, out[k], ref, exact)
+            else:
+                tol = 6e-5 * np.sqrt(max(n, 1)) + 1e-4 * float(np.max(np.abs(refs[k]))) if n else 0.0
+                assert float(np.max(np.abs(out[k] - refs[k]))) <= tol, (i, k, n, out[k], refs[k])

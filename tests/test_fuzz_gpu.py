@@ -188,3 +188,67 @@ def test_randomised_complex_and_16bit_codes(gctx, oracle):
             else:
                 tol = 6e-5 * np.sqrt(max(n, 1)) + 1e-4 * float(np.max(np.abs(refs[k]))) if n else 0.0
                 assert float(np.max(np.abs(out[k] - refs[k]))) <= tol, (i, k, n, out[k], refs[k])
+
+
+def test_randomised_ring_addressing(gctx, oracle):
+    """Random ring capacities, push sizes and window positions: correlating from the ring (absolute sample numbers, wrap,
+    mirrored head) must give what the same windows give from one linear buffer -- bit for bit when the capacity is even."""
+    import gnsscorr
+    import torch
+    rng = np.random.Generator(np.random.PCG64(909))
+    code = oracle.gps_l1_ca_code(13).astype(np.float32)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    for case in range(12):
+        fmt = [gnsscorr.GC_IQ_F32, gnsscorr.GC_IQ_I16, gnsscorr.GC_IQ_I8][case % 3]
+        win = int(rng.integers(64, 3000))
+        cap = int(rng.integers(2 * win, 6 * win))
+        total = int(rng.integers(3 * cap, 8 * cap))
+        raw = rng.standard_normal((total, 2))
+        if fmt == gnsscorr.GC_IQ_F32:
+            q = raw.astype(np.float32)
+            push_view = q.reshape(-1).view(np.complex64)
+        elif fmt == gnsscorr.GC_IQ_I16:
+            q = np.round(raw * 300).astype(np.int16)
+            push_view = q
+        else:
+            q = np.clip(np.round(raw * 30), -128, 127).astype(np.int8)
+            push_view = q
+        d_lin = torch.from_numpy(q).cuda()
+        lin = gnsscorr.TrackingBatch(gctx, 1, 3, 1023)
+        ring = gnsscorr.IqStream(gctx, cap, win, iq_format=fmt)
+        rb = gnsscorr.TrackingBatch(gctx, 1, 3, 1023)
+        for b in (lin, rb):
+            if fmt != gnsscorr.GC_IQ_F32:
+                b.set_input_format(fmt)
+            b.set_code(0, code, shifts)
+            b.set_slices(1)
+        lin.set_input_dev(0, d_lin.data_ptr(), total)
+        rb.set_input_stream(0, ring)
+        pushed = 0
+        while pushed < total:
+            m = int(min(rng.integers(1, cap + 1), total - pushed))
+            assert ring.push(push_view[pushed:pushed + m]) == pushed
+            pushed += m
+            oldest, head, _ = ring.info()
+            assert head == pushed and oldest == max(0, pushed - cap)
+            recs = []
+            for _ in range(6):
+                n = int(rng.integers(0, win + 1))
+                if head - oldest < n:
+                    continue
+                off = int(rng.integers(oldest, head - n + 1))
+                recs.append(gnsscorr.epoch_params(off, float(np.float32(rng.uniform(0, 6))), float(np.float32(rng.uniform(-0.01, 0.01))),
+                    float(np.float32(rng.uniform(-500, 500))), float(np.float32(rng.uniform(0.05, 0.5))), n))
+            if not recs:
+                continue
+            params = gnsscorr.epoch_params_array([recs])
+            got = rb.run(len(recs), params)
+            want = lin.run(len(recs), params)
+            if cap % 2 == 0:
+                assert np.array_equal(got, want), (case, cap, win, pushed, [(r.sample_offset, r.n_samples) for r in recs])
+            else:
+                # an odd capacity flips the pair alignment of wrapped windows: same samples, another summation order
+                assert np.max(np.abs(got - want)) <= 1e-5 * (1.0 + np.max(np.abs(want))), (case, cap, win, pushed)
+        lin.close()
+        rb.close()
+        ring.close()

@@ -252,3 +252,43 @@ def test_randomised_ring_addressing(gctx, oracle):
         lin.close()
         rb.close()
         ring.close()
+
+
+def test_randomised_level1_call_sequences(gctx, oracle):
+    """The drop-in object under random call sequences: window length changes from call to call, the caller edits the
+    shifts and the code table in place (pointers are retained, as in the reference), real / complex replicas alternate."""
+    import gnsscorr
+    rng = np.random.Generator(np.random.PCG64(31337))
+    n_max = 30000
+    sig = (rng.standard_normal(n_max + 64) + 1j * rng.standard_normal(n_max + 64)).astype(np.complex64)
+    for obj in range(6):
+        complex_code = (obj % 2 == 1)
+        n_taps = int(rng.integers(1, 9))
+        L = int(rng.choice([511, 1023, 2046, 4092]))
+        code = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64) if complex_code else np.sign(rng.standard_normal(L)).astype(np.float32)
+        shifts = np.sort(rng.uniform(-1, 1, n_taps)).astype(np.float32)
+        out = np.zeros(n_taps, np.complex64)
+        mc = gnsscorr.HipMulticorrelator(gctx) if complex_code else gnsscorr.HipMulticorrelatorRealCodes(gctx)
+        if not complex_code:
+            mc.set_high_dynamics_resampler(False)
+        mc.init(n_max, n_taps)
+        mc.set_local_code_and_taps(L, code, shifts)
+        for call in range(25):
+            n = int(rng.choice([0, 1, 100, 2000, 2048, 2049, 4000, 8000, 25000, int(rng.integers(0, n_max))]))
+            off = int(rng.integers(0, 33))
+            if rng.random() < 0.3:
+                shifts[:] = np.sort(rng.uniform(-1, 1, n_taps)).astype(np.float32)   # edited in place, no setter call
+            if rng.random() < 0.2:
+                code[int(rng.integers(0, L))] *= -1                                   # so is the replica
+            a = [np.float32(rng.uniform(-7, 7)), np.float32(rng.uniform(-0.02, 0.02)), np.float32(rng.uniform(-L, L)), np.float32(rng.uniform(0.02, 0.6))]
+            mc.set_input_output_vectors(out, sig[off:])
+            if complex_code:
+                mc.Carrier_wipeoff_multicorrelator_resampler(float(a[0]), float(a[1]), float(a[2]), float(a[3]), n)
+                ref = oracle.multicorrelator_cc(sig[off:], code, shifts, a[0], a[1], a[2], a[3], n)
+            else:
+                mc.Carrier_wipeoff_multicorrelator_resampler(float(a[0]), float(a[1]), 0.0, float(a[2]), float(a[3]), 0.0, n)
+                ref = oracle.multicorrelator(sig[off:], code, shifts, a[0], a[1], a[2], a[3], n)
+            tol = 6e-5 * np.sqrt(max(n, 1)) * (2.0 if complex_code else 1.0) + 1e-4 * float(np.max(np.abs(ref))) if n else 0.0
+            assert float(np.max(np.abs(out - ref))) <= tol, (obj, call, n, off, out, ref)
+        mc.free()
+        mc.close()

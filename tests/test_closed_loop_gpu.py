@@ -1,6 +1,8 @@
 """GPU parity of the closed-loop tracking engine (correlations + DLL/PLL maths of dll_pll_veml_tracking in one
 launch) against the Python restatement of the same loop running on the CPU oracle correlator
 (tests/closed_loop_ref.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -205,3 +207,38 @@ def test_closed_loop_on_the_real_glonass_capture(gctx, oracle):
     mag = np.abs(rec["corr"][:2, 0::2] + 1j * rec["corr"][:2, 1::2])[:, :3]
     assert np.all(mag[:, 1] > 1.25 * mag[:, 0]) and np.all(mag[:, 1] > 1.25 * mag[:, 2]) and np.all(mag[:, 1] > 700.0)
     assert np.all(np.abs(rec["carrier_doppler_hz"][:2] - g["expected_doppler_hz"]) < 50.0)
+
+
+def test_closed_loop_workgroup_sizes_agree(gctx, oracle):
+    """The device loop picks 1024 / 512 / 256 threads per channel from the channel count; the three variants track the
+    same signal to the same loop state (block boundaries identical, correlator sums equal to float rounding)."""
+    import gnsscorr
+    import torch
+    fs, n_ep = 4e6, 80
+    code, x = _signal(oracle, 17, fs, 4000 * (n_ep + 3), 123, -777.0, 3100.0)
+    conf = dict(GPS, acq_delay_samples=3100.0, acq_doppler_hz=-770.0, acq_samplestamp_samples=0, sample_counter=0)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    recs = {}
+    old = os.environ.get("GNSSCORR_LOOP_THREADS")
+    try:
+        for threads in (1024, 512, 256):
+            os.environ["GNSSCORR_LOOP_THREADS"] = str(threads)
+            loop = gnsscorr.TrackingLoop(gctx, 2, 1023)
+            for ch in range(2):
+                loop.set_input_dev(ch, d.data_ptr(), x.size)
+                loop.start(ch, _conf(gnsscorr, **conf), code)
+            recs[threads] = loop.run(n_ep)
+            loop.close()
+    finally:
+        if old is None:
+            os.environ.pop("GNSSCORR_LOOP_THREADS", None)
+        else:
+            os.environ["GNSSCORR_LOOP_THREADS"] = old
+    base = recs[1024]
+    assert np.all(base["valid"] == 1) and np.array_equal(base[0], base[1])  # two channels on the same signal: identical
+    for threads in (512, 256):
+        r = recs[threads]
+        assert np.array_equal(r["sample_counter"], base["sample_counter"])
+        assert np.array_equal(r["current_prn_length_samples"], base["current_prn_length_samples"])
+        assert np.max(np.abs(r["corr"] - base["corr"])) <= 2e-5 * np.max(np.abs(base["corr"]))
+        assert np.max(np.abs(r["carrier_doppler_hz"] - base["carrier_doppler_hz"])) < 0.02

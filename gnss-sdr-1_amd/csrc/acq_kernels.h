@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #define ACQ_MAX_FACTORS 12
-#define ACQ_MAX_N1 32
+#define ACQ_MAX_N1 64
 
 // N-point FFT as N = N1 x N2: N2-point row FFTs in LDS, N1-point column DFTs in registers
 struct AcqFftPlan

@@ -1076,7 +1076,7 @@ bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes)
     if (N < 1) return false;
     // N1 candidates (register DFT sizes that are instantiated); prefer rows of ~1000-2000 points:
     // long enough to occupy a 256-thread workgroup, short enough for several workgroups per CU
-    const int cands[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25};
+    const int cands[] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25, 32, 40, 50};  // 32-50: blocks of 256 k - 512 k samples
     int best = 0;
     long best_cost = -1;
     for (int n1 : cands)
@@ -1248,6 +1248,9 @@ hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const Acq
             CASE(16)
             CASE(20)
             CASE(25)
+            CASE(32)
+            CASE(40)
+            CASE(50)
 #undef CASE
         default:
             return hipErrorInvalidValue;

@@ -212,7 +212,7 @@ def test_cshort_input_block(gctx, oracle):
 
 # FFT sizes that walk every instantiated stage list of the packed row kernel (acq_rows2_registry in
 # acq_kernels.hip) and the general row kernel (prime radices 11 / 31, or a stage list outside the registry)
-@pytest.mark.parametrize("n", [2048, 5456, 6250, 8184, 12000, 24000, 30000, 32000, 32768, 40000, 50000, 64000, 65536, 80000, 100000])
+@pytest.mark.parametrize("n", [2048, 5456, 6250, 8184, 12000, 24000, 30000, 32000, 32768, 40000, 50000, 64000, 65536, 80000, 100000, 256000, 400000])
 def test_fft_sizes_against_oracle(gctx, oracle, n):
     import gnsscorr
     from helpers import synth_stream

@@ -9,8 +9,10 @@
 //   update_tracking_vars           dll_pll_veml_tracking.cc:998-1070
 //   pull-in alignment              dll_pll_veml_tracking.cc:1568-1600
 // so that a launch needs no host round trip per millisecond.  The per-epoch
-// record carries what the block puts in Gnss_Synchro and in its binary dump.  Not covered here
-// (host block image only): high-dynamics rate smoothing, telemetry/secondary-code synchronisation.
+// record carries what the block puts in Gnss_Synchro and in its binary dump.  The whole state machine of
+// general_work runs here: pull-in (1), wide tracking with secondary-code / preamble synchronisation (2,
+// :1601-1773), extended coherent integration (3, :1774-1826) and narrow tracking (4, :1827-1896), with the
+// data-component prompt correlator of pilot tracking (:899-910).  Not covered: high-dynamics rate smoothing.
 #include "gc_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -37,10 +39,27 @@ struct DevPll
     float w, x, a2, a3, b3, w0p, w0p2, w0p3, w0f, w0f2;
 };
 
+// gc_loop_sync_conf in device form: the bit patterns are stored newest-symbol-first (bit k = k-th newest symbol), the
+// order of the sign shift register they are compared with
+struct LoopSync
+{
+    int extend_symbols, track_pilot, symbols_per_bit, secondary_len, preamble_len;
+    float bit_sync_min_time_s, pll_bw_narrow_hz, dll_bw_narrow_hz, el_narrow_chips, vel_narrow_chips;
+    unsigned sec_ones[4];   // bit k set: secondary_code[len-1-k] == '1'
+    unsigned pre_plus[6];   // bit k set: preamble_symbols[len-1-k] == +1
+};
+
 // per-channel persistent state (device memory between launches, LDS during one)
 struct LoopChan
 {
     gc_loop_conf conf;
+    LoopSync sync;
+    unsigned hist[6];       // signs of the last prompts, newest in bit 0 (1 = negative real part): d_Prompt_circular_buffer /
+                            // d_symbol_history, of which only the signs are ever read
+    int hist_count;
+    float2 accu[5];         // d_VE_accu, d_E_accu, d_P_accu, d_L_accu, d_VL_accu
+    float2 prompt_data;     // d_Prompt_Data
+    int current_symbol, extend_count;
     TrkChan chan;       // iq, code table, taps
     int n_taps;
     int state;          // 0 standby, 1 pull-in, 2 tracking
@@ -151,6 +170,15 @@ static __device__ void pll_set_params(DevPll& p, float fll_bw_hz, float pll_bw_h
         }
 }
 
+// set_params on a running filter (:1754): new coefficients, integrators untouched
+static __device__ void pll_retune(DevPll& p, float fll_bw_hz, float pll_bw_hz, int order)
+{
+    const float w = p.w, x = p.x;
+    pll_set_params(p, fll_bw_hz, pll_bw_hz, order);
+    p.w = w;
+    p.x = x;
+}
+
 static __device__ float pll_get_carrier_error(DevPll& p, float fll, float pll, float T)
 {
     float carrier_error_hz;
@@ -212,10 +240,332 @@ static __device__ void loop_start(LoopChan& s)
     s.cloop = 1;
     s.pull_in_transitory = 1;
     s.lost_lock_events = 0;
+    for (int t = 0; t < 5; t++) s.accu[t] = make_float2(0.f, 0.f);
+    s.prompt_data = make_float2(0.f, 0.f);
+    s.current_symbol = 0;
+    s.extend_count = 0;
+    s.hist_count = 0;
+    for (int i = 0; i < 6; i++) s.hist[i] = 0u;
+}
+
+// cn0_and_tracking_lock_status (:839-878); false = loss of lock
+static __device__ bool loop_lock_status(LoopChan& s, double coh_integration_time_s)
+{
+    const gc_loop_conf& c = s.conf;
+    if (s.cn0_estimation_counter < c.cn0_samples)
+        {
+            s.prompt_buffer[s.cn0_estimation_counter] = s.accu[2];
+            s.cn0_estimation_counter++;
+            return true;
+        }
+    s.cn0_estimation_counter = 0;
+    double Psig = 0.0, Ptot = 0.0;
+    float sum_I = 0.f, sum_Q = 0.f;
+    for (int i = 0; i < c.cn0_samples; i++)
+        {
+            const float2 v = s.prompt_buffer[i];
+            Psig += fabs((double)v.x);
+            Ptot += (double)v.y * (double)v.y + (double)v.x * (double)v.x;
+            sum_I += v.x;
+            sum_Q += v.y;
+        }
+    Psig /= (double)c.cn0_samples;
+    Psig = Psig * Psig;
+    Ptot /= (double)c.cn0_samples;
+    const double SNR = Psig / (Ptot - Psig);
+    s.cn0_db_hz = (double)(float)(10.0 * log10(SNR) - 10.0 * log10(coh_integration_time_s));
+    const float NBP = sum_I * sum_I + sum_Q * sum_Q, NBD = sum_I * sum_I - sum_Q * sum_Q;
+    s.carrier_lock_test = (double)(NBD / NBP);
+    if (!s.pull_in_transitory)
+        {
+            if (s.carrier_lock_test < c.carrier_lock_th || s.cn0_db_hz < c.cn0_min)
+                s.carrier_lock_fail_counter++;
+            else if (s.carrier_lock_fail_counter > 0)
+                s.carrier_lock_fail_counter--;
+        }
+    if (s.carrier_lock_fail_counter > c.max_lock_fail)
+        {
+            s.lost_lock_events++;  // message 3 on the "events" port
+            s.carrier_lock_fail_counter = 0;
+            return false;
+        }
+    return true;
+}
+
+// clear_tracking_vars (:976-995)
+static __device__ void loop_clear_tracking_vars(LoopChan& s)
+{
+    s.prompt_data = make_float2(0.f, 0.f);
+    s.P_accu_old = make_float2(0.f, 0.f);
+    s.carr_phase_error_hz = s.carr_freq_error_hz = s.carr_error_filt_hz = 0.0;
+    s.code_error_chips = s.code_error_filt_chips = 0.0;
+    s.current_symbol = 0;
+    s.hist_count = 0;
+    for (int i = 0; i < 6; i++) s.hist[i] = 0u;
+}
+
+// run_dll_pll (:914-973) on the accumulators
+static __device__ void loop_run_dll_pll(LoopChan& s, bool veml)
+{
+    const gc_loop_conf& c = s.conf;
+    const float2 VE = s.accu[0], E = s.accu[1], P = s.accu[2], L = s.accu[3], VL = s.accu[4];
+    if (s.cloop)
+        s.carr_phase_error_hz = ((P.x != 0.0f) ? (double)atanf(P.y / P.x) : 0.0) / LOOP_PI_2;
+    else
+        s.carr_phase_error_hz = (double)atan2f(P.y, P.x) / LOOP_PI_2;
+    if ((s.pull_in_transitory && c.enable_fll_pull_in) || c.enable_fll_steady_state)
+        {
+            const double dot = s.P_accu_old.x * P.x + s.P_accu_old.y * P.y;
+            const double cross = s.P_accu_old.x * P.y - P.x * s.P_accu_old.y;
+            s.carr_freq_error_hz = atan2(cross, dot) / (s.current_correlation_time_s - 0.0) / LOOP_PI_2;
+            s.P_accu_old = P;
+            if (s.pull_in_transitory && c.enable_fll_pull_in)
+                s.carr_error_filt_hz = pll_get_carrier_error(s.pll, (float)s.carr_freq_error_hz, 0.0f, (float)s.current_correlation_time_s);
+            else
+                s.carr_error_filt_hz = pll_get_carrier_error(s.pll, (float)s.carr_freq_error_hz, (float)s.carr_phase_error_hz, (float)s.current_correlation_time_s);
+        }
+    else
+        s.carr_error_filt_hz = pll_get_carrier_error(s.pll, 0.0f, (float)s.carr_phase_error_hz, (float)s.current_correlation_time_s);
+    s.carrier_doppler_hz = s.carr_error_filt_hz;
+    if (veml)
+        {
+            const double pe = sqrt((double)(VE.x * VE.x + VE.y * VE.y) + (double)(E.x * E.x + E.y * E.y));
+            const double pl = sqrt((double)(VL.x * VL.x + VL.y * VL.y) + (double)(L.x * L.x + L.y * L.y));
+            s.code_error_chips = (pe + pl == 0.0) ? 0.0 : (pe - pl) / (pe + pl);
+        }
+    else
+        {
+            const double pe = cabs_d(E), pl = cabs_d(L);
+            s.code_error_chips = (pe + pl == 0.0) ? 0.0 : 0.5 * (pe - pl) / (pe + pl);
+        }
+    s.code_error_filt_chips = dll_apply(s.dll, (float)s.code_error_chips);
+    s.code_freq_chips = (1.0 + (s.carrier_doppler_hz / c.signal_carrier_freq_hz)) * c.code_chip_rate_hz - s.code_error_filt_chips;
+}
+
+// update_tracking_vars (:998-1070), no high-dynamics terms
+static __device__ void loop_update_tracking_vars(LoopChan& s)
+{
+    const gc_loop_conf& c = s.conf;
+    const double T_prn_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
+    const double K_blk_samples = T_prn_samples + s.rem_code_phase_samples;
+    s.current_prn_length_samples = (int)floor(K_blk_samples);
+    s.carrier_phase_step_rad = LOOP_PI_2 * s.carrier_doppler_hz / c.fs_in;
+    const double n = (double)s.current_prn_length_samples;
+    s.rem_carr_phase_rad += (float)(s.carrier_phase_step_rad * n);
+    s.rem_carr_phase_rad = fmodf(s.rem_carr_phase_rad, (float)LOOP_PI_2);
+    s.acc_carrier_phase_rad -= s.carrier_phase_step_rad * n;
+    s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+    s.rem_code_phase_samples = K_blk_samples - n;
+    s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
+}
+
+// save_correlation_results (:1072-1125): accumulate with the secondary-code sign
+static __device__ void loop_save_correlation_results(LoopChan& s, const float2* taps, bool veml)
+{
+    const LoopSync& y = s.sync;
+    float sign = 1.0f;
+    if (y.secondary_len > 0)
+        {
+            // sec_ones is stored newest-first: character i of the string is bit (len - 1 - i)
+            const int bit = y.secondary_len - 1 - s.current_symbol;
+            if ((y.sec_ones[bit >> 5] >> (bit & 31)) & 1u) sign = -1.0f;
+            s.current_symbol = (s.current_symbol + 1) % y.secondary_len;
+        }
+    else
+        {
+            s.current_symbol++;
+            s.current_symbol = y.symbols_per_bit > 0 ? s.current_symbol % y.symbols_per_bit : 0;
+        }
+    for (int t = 0; t < 5; t++)
+        {
+            if (!veml && (t == 0 || t == 4)) continue;
+            const float2 v = taps[veml ? t : t - 1];
+            if (sign > 0.0f)
+                {
+                    s.accu[t].x += v.x;
+                    s.accu[t].y += v.y;
+                }
+            else
+                {
+                    s.accu[t].x -= v.x;
+                    s.accu[t].y -= v.y;
+                }
+        }
+    s.cloop = y.track_pilot ? 0 : 1;
+}
+
+// pushes the sign of the prompt into the history; true when the last `len` signs match `pattern`
+// (exactly == all bits equal; or, for the secondary code, all bits opposite as well)
+static __device__ bool loop_push_and_match(LoopChan& s, float prompt_re, int len, const unsigned* pattern, bool either_polarity)
+{
+    const unsigned neg = prompt_re < 0.0f ? 1u : 0u;
+    for (int w = 5; w > 0; w--) s.hist[w] = (s.hist[w] << 1) | (s.hist[w - 1] >> 31);
+    s.hist[0] = (s.hist[0] << 1) | neg;
+    if (s.hist_count < len) s.hist_count++;
+    if (s.hist_count < len) return false;
+    int diff = 0;
+    for (int w = 0; w * 32 < len; w++)
+        {
+            const int nb = min(32, len - w * 32);
+            const unsigned mask = nb == 32 ? 0xffffffffu : ((1u << nb) - 1u);
+            diff += __popc((s.hist[w] ^ pattern[w]) & mask);
+        }
+    return either_polarity ? (diff == 0 || diff == len) : diff == len;
+}
+
+static __device__ void loop_write_record(const LoopChan& s, gc_loop_record* rec, int valid, int integrating, int extend_count)
+{
+    for (int t = 0; t < 5; t++)
+        {
+            rec->accu[2 * t] = s.accu[t].x;
+            rec->accu[2 * t + 1] = s.accu[t].y;
+        }
+    rec->extend_count = extend_count;
+    rec->integrating = integrating;
+    rec->valid = valid;
+}
+
+// everything general_work does with one code period's correlator outputs (states 2, 3, 4; :1601-1896)
+template <int NTAPS, bool DATA>
+static __device__ void loop_after_correlation(LoopChan& s, const float2* taps, gc_loop_record* rec)
+{
+    const gc_loop_conf& c = s.conf;
+    const LoopSync& y = s.sync;
+    const bool veml = NTAPS == 5;
+    const float2 P = taps[NTAPS / 2];
+    {
+        unsigned* w = reinterpret_cast<unsigned*>(rec);
+        for (unsigned i = 0; i < sizeof(gc_loop_record) / 4; i++) w[i] = 0u;
+    }
+    for (int t = 0; t < NTAPS; t++)
+        {
+            rec->corr[2 * t] = taps[t].x;
+            rec->corr[2 * t + 1] = taps[t].y;
+        }
+    s.prompt_data = DATA ? taps[NTAPS] : P;
+    const int ext = y.extend_symbols > 1 ? y.extend_symbols : 1;
+    if (s.state == 2)
+        {
+            // single correlation step variables (:1604-1612)
+            for (int t = 0; t < 5; t++) s.accu[t] = make_float2(0.f, 0.f);
+            for (int t = 0; t < NTAPS; t++) s.accu[veml ? t : t + 1] = taps[t];
+            if (!loop_lock_status(s, c.code_period_s))
+                {
+                    loop_clear_tracking_vars(s);
+                    s.state = 0;
+                    loop_write_record(s, rec, 0, 0, 0);
+                }
+            else
+                {
+                    loop_run_dll_pll(s, veml);
+                    loop_update_tracking_vars(s);
+                    loop_write_record(s, rec, 1, 0, s.extend_count);  // log_data(false), :1627
+                    bool next_state;
+                    if (y.secondary_len > 0)
+                        {
+                            // acquire_secondary (:800-836) over the last secondary_len prompts: '0' <-> positive prompt or the
+                            // exact opposite.  A negative prompt on a '0' counts +1: sign bit == 1 and code bit == 0 differ.
+                            next_state = loop_push_and_match(s, P.x, y.secondary_len, y.sec_ones, true);
+                        }
+                    else if (y.symbols_per_bit > 1)
+                        {
+                            // preamble search after bit_sync_min_time_s of tracking (:1645-1685)
+                            next_state = false;
+                            const float t_trk = (float)((double)(float)(s.sample_counter - s.acq_sample_stamp) / c.fs_in);
+                            if (t_trk > y.bit_sync_min_time_s && y.preamble_len > 0)
+                                {
+                                    // corr == length  <=>  every symbol's clipped sign equals the preamble's: negative
+                                    // (bit 1) where the preamble is -1 (pre_plus bit 0): all bits differ
+                                    next_state = loop_push_and_match(s, P.x, y.preamble_len, y.pre_plus, false);
+                                }
+                        }
+                    else
+                        next_state = true;
+                    if (next_state)
+                        {
+                            for (int t = 0; t < 5; t++) s.accu[t] = make_float2(0.f, 0.f);
+                            s.hist_count = 0;
+                            for (int i = 0; i < 6; i++) s.hist[i] = 0u;
+                            s.current_symbol = 0;
+                            if (ext > 1)
+                                {
+                                    s.extend_count = 0;
+                                    s.current_correlation_time_s = (double)((float)ext * (float)c.code_period_s);
+                                    s.state = 3;
+                                    // narrow loop filters and taps (:1751-1766)
+                                    dll_design(s.dll, c.dll_filter_order, y.dll_bw_narrow_hz, (float)s.current_correlation_time_s);
+                                    pll_retune(s.pll, c.fll_bw_hz, y.pll_bw_narrow_hz, c.pll_filter_order);
+                                    const float spc = (float)c.code_samples_per_chip;
+                                    if (veml)
+                                        {
+                                            s.chan.shifts[0] = -y.vel_narrow_chips * spc;
+                                            s.chan.shifts[1] = -y.el_narrow_chips * spc;
+                                            s.chan.shifts[3] = y.el_narrow_chips * spc;
+                                            s.chan.shifts[4] = y.vel_narrow_chips * spc;
+                                        }
+                                    else
+                                        {
+                                            s.chan.shifts[0] = -y.el_narrow_chips * spc;
+                                            s.chan.shifts[2] = y.el_narrow_chips * spc;
+                                        }
+                                }
+                            else
+                                s.state = 4;
+                        }
+                }
+        }
+    else if (s.state == 3)
+        {
+            loop_update_tracking_vars(s);
+            loop_save_correlation_results(s, taps, veml);
+            s.extend_count++;
+            if (s.extend_count == ext - 1)
+                {
+                    s.extend_count = 0;
+                    s.state = 4;
+                }
+            loop_write_record(s, rec, 1, 1, s.extend_count);  // log_data(true), :1824
+        }
+    else  // state 4
+        {
+            loop_save_correlation_results(s, taps, veml);
+            if (!loop_lock_status(s, c.code_period_s * (double)ext))
+                {
+                    loop_clear_tracking_vars(s);
+                    s.state = 0;
+                    loop_write_record(s, rec, 0, 0, 0);
+                }
+            else
+                {
+                    loop_run_dll_pll(s, veml);
+                    loop_update_tracking_vars(s);
+                    loop_write_record(s, rec, 1, 0, s.extend_count);  // log_data(false), :1880
+                    for (int t = 0; t < 5; t++) s.accu[t] = make_float2(0.f, 0.f);
+                    if (ext > 1) s.state = 3;
+                }
+        }
+    s.sample_counter += (unsigned long long)s.current_prn_length_samples;
+    s.pos += (unsigned long long)s.current_prn_length_samples;
+    rec->prompt_data[0] = s.prompt_data.x;
+    rec->prompt_data[1] = s.prompt_data.y;
+    rec->sample_counter = s.sample_counter;
+    rec->acc_carrier_phase_rad = s.acc_carrier_phase_rad;
+    rec->rem_code_phase_samples = s.rem_code_phase_samples;
+    rec->carrier_doppler_hz = (float)s.carrier_doppler_hz;
+    rec->code_freq_chips = (float)s.code_freq_chips;
+    rec->carr_phase_error_hz = (float)s.carr_phase_error_hz;
+    rec->carr_error_filt_hz = (float)s.carr_error_filt_hz;
+    rec->code_error_chips = (float)s.code_error_chips;
+    rec->code_error_filt_chips = (float)s.code_error_filt_chips;
+    rec->cn0_db_hz = (float)s.cn0_db_hz;
+    rec->carrier_lock_test = (float)s.carrier_lock_test;
+    rec->state = s.state;
+    rec->current_prn_length_samples = s.current_prn_length_samples;
 }
 
 // THREADS per channel: 1024 when there are few channels (one workgroup per CU), 256 when there are many
-template <int NTAPS, int THREADS, int FMT>
+// DATA: pilot tracking, every channel carries the data component's replica (chan.code2)
+template <int NTAPS, int THREADS, int FMT, bool DATA>
 __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
     gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats, const unsigned long long* __restrict__ limits)
 {
@@ -297,141 +647,11 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
             __syncthreads();
             if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
 
-            const float2 r = trk_epoch<NTAPS, false, false, FMT, false, false, THREADS>(s.chan, s_p, 0, 1, lds_table_floats, lds);
-            if (tid < NTAPS) s_corr[tid] = r;
+            const float2 r = trk_epoch<NTAPS, false, false, FMT, false, false, THREADS, DATA>(s.chan, s_p, 0, 1, lds_table_floats, lds);
+            if (tid < NTAPS + (DATA ? 1 : 0)) s_corr[tid] = r;
             __syncthreads();
 
-            if (tid == 0)
-                {
-                    const gc_loop_conf& c = s.conf;
-                    const bool veml = NTAPS == 5;
-                    const float2 VE = veml ? s_corr[0] : make_float2(0.f, 0.f);
-                    const float2 VL = veml ? s_corr[4] : make_float2(0.f, 0.f);
-                    const float2 E = s_corr[veml ? 1 : 0], P = s_corr[veml ? 2 : 1], L = s_corr[veml ? 3 : 2];
-                    {
-                        unsigned* w = reinterpret_cast<unsigned*>(rec);
-                        for (unsigned i = 0; i < sizeof(gc_loop_record) / 4; i++) w[i] = 0u;
-                    }
-                    for (int t = 0; t < NTAPS; t++)
-                        {
-                            rec->corr[2 * t] = s_corr[t].x;
-                            rec->corr[2 * t + 1] = s_corr[t].y;
-                        }
-                    int valid = 0;
-                    // ---- cn0_and_tracking_lock_status (:839-878) ----
-                    bool locked = true;
-                    if (s.cn0_estimation_counter < c.cn0_samples)
-                        {
-                            s.prompt_buffer[s.cn0_estimation_counter] = P;
-                            s.cn0_estimation_counter++;
-                        }
-                    else
-                        {
-                            s.cn0_estimation_counter = 0;
-                            double Psig = 0.0, Ptot = 0.0;
-                            float sum_I = 0.f, sum_Q = 0.f;
-                            for (int i = 0; i < c.cn0_samples; i++)
-                                {
-                                    const float2 v = s.prompt_buffer[i];
-                                    Psig += fabs((double)v.x);
-                                    Ptot += (double)v.y * (double)v.y + (double)v.x * (double)v.x;
-                                    sum_I += v.x;
-                                    sum_Q += v.y;
-                                }
-                            Psig /= (double)c.cn0_samples;
-                            Psig = Psig * Psig;
-                            Ptot /= (double)c.cn0_samples;
-                            const double SNR = Psig / (Ptot - Psig);
-                            s.cn0_db_hz = (double)(float)(10.0 * log10(SNR) - 10.0 * log10(c.code_period_s));
-                            const float NBP = sum_I * sum_I + sum_Q * sum_Q, NBD = sum_I * sum_I - sum_Q * sum_Q;
-                            s.carrier_lock_test = (double)(NBD / NBP);
-                            if (!s.pull_in_transitory)
-                                {
-                                    if (s.carrier_lock_test < c.carrier_lock_th || s.cn0_db_hz < c.cn0_min)
-                                        s.carrier_lock_fail_counter++;
-                                    else if (s.carrier_lock_fail_counter > 0)
-                                        s.carrier_lock_fail_counter--;
-                                }
-                            if (s.carrier_lock_fail_counter > c.max_lock_fail)
-                                {
-                                    s.lost_lock_events++;  // message 3 on the "events" port
-                                    s.carrier_lock_fail_counter = 0;
-                                    locked = false;
-                                }
-                        }
-                    if (!locked)
-                        {
-                            // clear_tracking_vars (:976-995) + standby
-                            s.P_accu_old = make_float2(0.f, 0.f);
-                            s.carr_phase_error_hz = s.carr_freq_error_hz = s.carr_error_filt_hz = 0.0;
-                            s.code_error_chips = s.code_error_filt_chips = 0.0;
-                            s.state = 0;
-                        }
-                    else
-                        {
-                            // ---- run_dll_pll (:914-973) ----
-                            if (s.cloop)
-                                s.carr_phase_error_hz = ((P.x != 0.0f) ? (double)atanf(P.y / P.x) : 0.0) / LOOP_PI_2;
-                            else
-                                s.carr_phase_error_hz = (double)atan2f(P.y, P.x) / LOOP_PI_2;
-                            if ((s.pull_in_transitory && c.enable_fll_pull_in) || c.enable_fll_steady_state)
-                                {
-                                    const double dot = s.P_accu_old.x * P.x + s.P_accu_old.y * P.y;
-                                    const double cross = s.P_accu_old.x * P.y - P.x * s.P_accu_old.y;
-                                    s.carr_freq_error_hz = atan2(cross, dot) / (s.current_correlation_time_s - 0.0) / LOOP_PI_2;
-                                    s.P_accu_old = P;
-                                    if (s.pull_in_transitory && c.enable_fll_pull_in)
-                                        s.carr_error_filt_hz = pll_get_carrier_error(s.pll, (float)s.carr_freq_error_hz, 0.0f, (float)s.current_correlation_time_s);
-                                    else
-                                        s.carr_error_filt_hz = pll_get_carrier_error(s.pll, (float)s.carr_freq_error_hz, (float)s.carr_phase_error_hz, (float)s.current_correlation_time_s);
-                                }
-                            else
-                                s.carr_error_filt_hz = pll_get_carrier_error(s.pll, 0.0f, (float)s.carr_phase_error_hz, (float)s.current_correlation_time_s);
-                            s.carrier_doppler_hz = s.carr_error_filt_hz;
-                            if (veml)
-                                {
-                                    const double pe = sqrt((double)(VE.x * VE.x + VE.y * VE.y) + (double)(E.x * E.x + E.y * E.y));
-                                    const double pl = sqrt((double)(VL.x * VL.x + VL.y * VL.y) + (double)(L.x * L.x + L.y * L.y));
-                                    s.code_error_chips = (pe + pl == 0.0) ? 0.0 : (pe - pl) / (pe + pl);
-                                }
-                            else
-                                {
-                                    const double pe = cabs_d(E), pl = cabs_d(L);
-                                    s.code_error_chips = (pe + pl == 0.0) ? 0.0 : 0.5 * (pe - pl) / (pe + pl);
-                                }
-                            s.code_error_filt_chips = dll_apply(s.dll, (float)s.code_error_chips);
-                            s.code_freq_chips = (1.0 + (s.carrier_doppler_hz / c.signal_carrier_freq_hz)) * c.code_chip_rate_hz - s.code_error_filt_chips;
-                            // ---- update_tracking_vars (:998-1070), no high-dynamics terms ----
-                            const double T_prn_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
-                            const double K_blk_samples = T_prn_samples + s.rem_code_phase_samples;
-                            s.current_prn_length_samples = (int)floor(K_blk_samples);
-                            s.carrier_phase_step_rad = LOOP_PI_2 * s.carrier_doppler_hz / c.fs_in;
-                            const double n = (double)s.current_prn_length_samples;
-                            s.rem_carr_phase_rad += (float)(s.carrier_phase_step_rad * n);
-                            s.rem_carr_phase_rad = fmodf(s.rem_carr_phase_rad, (float)LOOP_PI_2);
-                            s.acc_carrier_phase_rad -= s.carrier_phase_step_rad * n;
-                            s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
-                            s.rem_code_phase_samples = K_blk_samples - n;
-                            s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
-                            valid = 1;
-                        }
-                    s.sample_counter += (unsigned long long)s.current_prn_length_samples;
-                    s.pos += (unsigned long long)s.current_prn_length_samples;
-                    rec->sample_counter = s.sample_counter;
-                    rec->acc_carrier_phase_rad = s.acc_carrier_phase_rad;
-                    rec->rem_code_phase_samples = s.rem_code_phase_samples;
-                    rec->carrier_doppler_hz = (float)s.carrier_doppler_hz;
-                    rec->code_freq_chips = (float)s.code_freq_chips;
-                    rec->carr_phase_error_hz = (float)s.carr_phase_error_hz;
-                    rec->carr_error_filt_hz = (float)s.carr_error_filt_hz;
-                    rec->code_error_chips = (float)s.code_error_chips;
-                    rec->code_error_filt_chips = (float)s.code_error_filt_chips;
-                    rec->cn0_db_hz = (float)s.cn0_db_hz;
-                    rec->carrier_lock_test = (float)s.carrier_lock_test;
-                    rec->state = s.state;
-                    rec->valid = valid;
-                    rec->current_prn_length_samples = s.current_prn_length_samples;
-                }
+            if (tid == 0) loop_after_correlation<NTAPS, DATA>(s, s_corr, rec);
             // the next iteration's barrier orders these writes before any other thread reads s / s_p again
         }
     __syncthreads();
@@ -457,6 +677,10 @@ struct gc_trk_loop
     int n_channels = 0, max_code_len = 0, n_taps = 0;
     LoopChan* d_chans = nullptr;
     float* d_codes = nullptr;
+    float* d_data_codes = nullptr;            // pilot tracking: data-component replicas, allocated on first use
+    std::vector<LoopSync> sync;               // per channel (gc_trk_loop_set_sync); extend_symbols == 0: none installed
+    std::vector<char> has_data_code;
+    int pilot = -1;                           // pilot mode of the started channels (-1: none started yet)
     gc_loop_record* d_recs = nullptr;
     size_t recs_cap = 0;
     int forced_threads = 0;  // $GNSSCORR_LOOP_THREADS (256 / 512 / 1024): tuning knob
@@ -502,6 +726,8 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
         }
     (void)hipMemset(l->d_chans, 0, sizeof(LoopChan) * n_channels);
     l->started.assign(n_channels, 0);
+    l->sync.assign(n_channels, LoopSync());
+    l->has_data_code.assign(n_channels, 0);
     l->iq.assign(n_channels, nullptr);
     l->n_iq.assign(n_channels, 0);
     l->streams.assign(n_channels, nullptr);
@@ -527,6 +753,7 @@ gc_status gc_trk_loop_destroy(gc_trk_loop* l)
     (void)hipStreamSynchronize(l->ctx->stream);
     (void)hipFree(l->d_chans);
     (void)hipFree(l->d_codes);
+    (void)hipFree(l->d_data_codes);
     (void)hipFree(l->d_recs);
     (void)hipFree(l->d_limits);
     if (l->h_limits) (void)hipHostFree(l->h_limits);
@@ -592,6 +819,65 @@ gc_status gc_trk_loop_set_input_stream(gc_trk_loop* l, int ch, gc_stream* s)
     return GC_OK;
 }
 
+gc_status gc_trk_loop_set_sync(gc_trk_loop* l, int ch, const gc_loop_sync_conf* sync, const float* data_code, int data_code_length)
+{
+    GC_REQUIRE(l, "gc_trk_loop_set_sync: NULL handle");
+    GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_set_sync: channel %d out of range", ch);
+    if (!sync)
+        {
+            std::lock_guard<std::mutex> lk(l->ctx->mtx);
+            l->sync[ch] = LoopSync();
+            l->has_data_code[ch] = 0;
+            return GC_OK;
+        }
+    GC_REQUIRE(sync->extend_correlation_symbols >= 1, "gc_trk_loop_set_sync: extend_correlation_symbols must be >= 1");
+    GC_REQUIRE(sync->secondary_code_length >= 0 && sync->secondary_code_length <= 128, "gc_trk_loop_set_sync: secondary_code_length must be in 0..128");
+    GC_REQUIRE(sync->preamble_length_symbols >= 0 && sync->preamble_length_symbols <= 192, "gc_trk_loop_set_sync: preamble_length_symbols must be in 0..192");
+    GC_REQUIRE(sync->symbols_per_bit >= 0, "gc_trk_loop_set_sync: symbols_per_bit must be >= 0");
+    LoopSync y;
+    std::memset(&y, 0, sizeof y);
+    y.extend_symbols = sync->extend_correlation_symbols;
+    y.track_pilot = sync->track_pilot ? 1 : 0;
+    y.symbols_per_bit = sync->symbols_per_bit;
+    y.secondary_len = sync->secondary_code_length;
+    y.preamble_len = sync->preamble_length_symbols;
+    y.bit_sync_min_time_s = sync->bit_sync_min_time_s;
+    y.pll_bw_narrow_hz = sync->pll_bw_narrow_hz;
+    y.dll_bw_narrow_hz = sync->dll_bw_narrow_hz;
+    y.el_narrow_chips = sync->early_late_space_narrow_chips;
+    y.vel_narrow_chips = sync->very_early_late_space_narrow_chips;
+    for (int i = 0; i < y.secondary_len; i++)
+        {
+            const char ch_i = sync->secondary_code[i];
+            GC_REQUIRE(ch_i == '0' || ch_i == '1', "gc_trk_loop_set_sync: secondary_code[%d] is not '0' or '1'", i);
+            const int bit = y.secondary_len - 1 - i;  // newest symbol in bit 0
+            if (ch_i == '1') y.sec_ones[bit >> 5] |= 1u << (bit & 31);
+        }
+    for (int i = 0; i < y.preamble_len; i++)
+        {
+            const int v = sync->preamble_symbols[i];
+            GC_REQUIRE(v == 1 || v == -1, "gc_trk_loop_set_sync: preamble_symbols[%d] is not +1 / -1", i);
+            const int bit = y.preamble_len - 1 - i;
+            if (v == 1) y.pre_plus[bit >> 5] |= 1u << (bit & 31);
+        }
+    gc_device_guard g(l->ctx->device);
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    if (y.track_pilot)
+        {
+            GC_REQUIRE(data_code, "gc_trk_loop_set_sync: track_pilot needs the data component's replica");
+            GC_REQUIRE(data_code_length > 0 && data_code_length <= l->max_code_len, "gc_trk_loop_set_sync: data_code_length %d not in 1..%d", data_code_length,
+                l->max_code_len);
+            if (!l->d_data_codes) GC_HIP(hipMalloc(&l->d_data_codes, sizeof(float) * (size_t)l->n_channels * l->max_code_len));
+            GC_HIP(hipStreamSynchronize(l->ctx->stream));
+            GC_HIP(hipMemcpy(l->d_data_codes + (size_t)ch * l->max_code_len, data_code, sizeof(float) * data_code_length, hipMemcpyHostToDevice));
+            l->has_data_code[ch] = 1;
+            // the table that follows code_length floats of replica must be the same length: checked at start
+            y.track_pilot = data_code_length;  // carried to gc_trk_loop_start, normalised to 1 there
+        }
+    l->sync[ch] = y;
+    return GC_OK;
+}
+
 gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, const float* code, int code_length)
 {
     GC_REQUIRE(l && conf && code, "gc_trk_loop_start: NULL argument");
@@ -607,12 +893,33 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
     GC_REQUIRE(l->n_taps == n_taps, "gc_trk_loop_start: all channels of one loop engine use the same tap count (%d)", l->n_taps);
     gc_device_guard g(l->ctx->device);
     std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    LoopSync y = l->sync[ch];
+    if (y.extend_symbols == 0)
+        {
+            // nothing installed: a signal whose bit synchronisation never happens (stays in state 2)
+            y.extend_symbols = 1;
+            y.symbols_per_bit = 2;
+        }
+    if (y.track_pilot)
+        {
+            GC_REQUIRE(y.track_pilot == code_length, "gc_trk_loop_start: the data replica has %d samples, the tracking replica %d", y.track_pilot, code_length);
+            y.track_pilot = 1;
+        }
+    {
+        bool others_started = false;
+        for (int i = 0; i < l->n_channels; i++) others_started |= (i != ch && l->started[i]);
+        if (!others_started) l->pilot = -1;
+    }
+    if (l->pilot < 0) l->pilot = y.track_pilot;
+    GC_REQUIRE(l->pilot == y.track_pilot, "gc_trk_loop_start: all channels of one loop engine share the pilot mode (track_pilot = %d)", l->pilot);
     hipStream_t st = l->ctx->stream;
     GC_HIP(hipStreamSynchronize(st));
     GC_HIP(hipMemcpy(l->d_codes + (size_t)ch * l->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
     LoopChan h;
     std::memset(&h, 0, sizeof h);
     h.conf = *conf;
+    h.sync = y;
+    h.chan.code2 = y.track_pilot ? l->d_data_codes + (size_t)ch * l->max_code_len : nullptr;
     h.chan.iq = l->iq[ch];
     h.chan.n_iq = l->n_iq[ch];
     h.chan.code = l->d_codes + (size_t)ch * l->max_code_len;
@@ -691,14 +998,30 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
             GC_HIP(hipMemcpyAsync(l->d_limits, l->h_limits, sizeof(unsigned long long) * l->n_channels, hipMemcpyHostToDevice, st));
         }
     const unsigned long long* limits = any_ring ? l->d_limits : nullptr;
-    const int lds_table_floats = l->max_code_len + 64;
+    const bool pilot = l->pilot > 0;
+    const int lds_table_floats = (l->max_code_len + 64) * (pilot ? 2 : 1);
     // few channels: more threads each, so that a channel's epoch is spread over a whole CU (measured, 256 channels x 64
     // epochs on 256 CUs: 0.89 / 0.65 / 0.69 ms with 256 / 512 / 1024 threads)
     const int n_cus = l->ctx->n_cus > 0 ? l->ctx->n_cus : 256;
     const int threads = l->forced_threads ? l->forced_threads : (2 * l->n_channels <= n_cus ? 1024 : l->n_channels <= 2 * n_cus ? 512 : 256);
     const size_t lds_bytes = (size_t)(trk_hdr_floats(threads) + lds_table_floats) * sizeof(float);
-#define LAUNCH_LOOP(NT, TH, FM) \
-    hipLaunchKernelGGL((trk_closed_loop_kernel<NT, TH, FM>), dim3(l->n_channels), dim3(TH), lds_bytes, st, l->d_chans, dev_records, n_epochs, lds_table_floats, limits)
+#define LAUNCH_LOOP_D(NT, TH, FM, DA)                                                                                                             \
+    do                                                                                                                                        \
+        {                                                                                                                                     \
+            if (lds_bytes > 48 * 1024)                                                                                                        \
+                GC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, TH, FM, DA>),                            \
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                                                             \
+            hipLaunchKernelGGL((trk_closed_loop_kernel<NT, TH, FM, DA>), dim3(l->n_channels), dim3(TH), lds_bytes, st, l->d_chans, dev_records, \
+                n_epochs, lds_table_floats, limits);                                                                                          \
+        }                                                                                                                                     \
+    while (0)
+#define LAUNCH_LOOP(NT, TH, FM)                      \
+    do                                               \
+        {                                            \
+            if (pilot) LAUNCH_LOOP_D(NT, TH, FM, true); \
+            else LAUNCH_LOOP_D(NT, TH, FM, false);   \
+        }                                            \
+    while (0)
 #define LAUNCH_LOOP_FMT(NT, TH)                                           \
     do                                                                    \
         {                                                                 \
@@ -721,6 +1044,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
         }
 #undef LAUNCH_LOOP_FMT
 #undef LAUNCH_LOOP
+#undef LAUNCH_LOOP_D
     GC_HIP(hipGetLastError());
     for (size_t k = 0; k < rings.size(); k++)
         {

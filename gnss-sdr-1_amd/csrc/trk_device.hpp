@@ -158,15 +158,22 @@ static __device__ __forceinline__ int floor_to_int(float x)
 //             reference's lv_16sc_t product) and accumulated in 32-bit integers; the table holds one
 //             (re16, im16) pair per 4-byte word and the accumulators carry integer bit patterns
 //   THREADS : workgroup size (a multiple of 64); a chunk is 2*THREADS samples
-template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS>
+//   DATA    : pilot tracking (dll_pll_veml_tracking.cc:899-910): a second, prompt-only correlator on the data
+//             component's replica, slaved to the pilot prompt tap (same shift pointer, same NCO scalars, hence
+//             the same chip index): table2 holds the data replica laid out like `table`; its sum goes to
+//             accr[NTAPS] / acci[NTAPS] (plain float mode only)
+template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false>
 static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
     int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
-    float (&accr)[NTAPS], float (&acci)[NTAPS])
+    float (&accr)[NTAPS + (DATA ? 1 : 0)], float (&acci)[NTAPS + (DATA ? 1 : 0)], const float* __restrict__ table2 = nullptr)
 {
+    static_assert(!DATA || (!HDR && !HDC && !CC && !SC16), "the data-component correlator exists in the plain float mode only");
     constexpr int CHUNK = 2 * THREADS;
+    constexpr int PT = NTAPS / 2;  // prompt tap of E/P/L and VE/E/P/L/VL
     const int tid = threadIdx.x;
     const float* tl = table - (CC ? 2 * lo : lo);  // windowed lookups index with the unwrapped chip number
+    const float* tl2 = DATA ? table2 - lo : nullptr;
     // one tap, one sample: acc += y * code[i]
     auto mac = [&](float yr, float yi, int i, float& ar, float& ai) {
         if (SC16)
@@ -331,6 +338,16 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
                         const int i1 = floor_to_int((s1 + shifts[t]) - rem);
                         mac(y0r, y0i, i0, accr[t], acci[t]);
                         mac(y1r, y1i, i1, accr[t], acci[t]);
+                        if constexpr (DATA)
+                            if (t == PT)
+                            {
+                                const float d0 = WINDOWED ? tl2[i0] : table2[posmod(i0, L)];
+                                const float d1 = WINDOWED ? tl2[i1] : table2[posmod(i1, L)];
+                                accr[NTAPS] = fmaf(y0r, d0, accr[NTAPS]);
+                                acci[NTAPS] = fmaf(y0i, d0, acci[NTAPS]);
+                                accr[NTAPS] = fmaf(y1r, d1, accr[NTAPS]);
+                                acci[NTAPS] = fmaf(y1i, d1, acci[NTAPS]);
+                            }
                     }
             }
         if (!HDC)
@@ -402,7 +419,9 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 // Every thread of the 256-thread workgroup must call it; the sum of tap `tid` is returned to the threads
 // with tid < NTAPS (others get 0).  lds: trk_hdr_floats(THREADS) + lds_table_floats floats of dynamic LDS.
 // With SC16 the returned pair holds the two 32-bit integer sums as bit patterns.
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS>
+// With DATA (pilot tracking) cd.code2 is the data component's replica: its prompt sum is returned to tid == NTAPS and the
+// window needs 2x the LDS floats.
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
     int lds_table_floats, float* lds)
 {
@@ -513,9 +532,13 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
         }
     const long long span_ll = (long long)hi - (long long)lo + 1;
     typedef typename std::conditional<CC, f32x2, float>::type chip_t;
-    const bool windowed = monotone && span_ll > 0 && span_ll * (long long)(sizeof(chip_t) / sizeof(float)) <= (long long)lds_table_floats;
+    const bool windowed = monotone && span_ll > 0 && span_ll * (long long)(sizeof(chip_t) / sizeof(float)) * (DATA ? 2 : 1) <= (long long)lds_table_floats;
     const GC_GLOBAL chip_t* code = (const GC_GLOBAL chip_t*)cd.code;
     chip_t* table_c = reinterpret_cast<chip_t*>(table);
+    // data-component replica (pilot tracking): same layout, right behind the pilot's table
+    constexpr int NACC = NTAPS + (DATA ? 1 : 0);
+    float* table2 = DATA ? table + (windowed ? (int)span_ll : L) : nullptr;
+    const GC_GLOBAL float* code2 = (const GC_GLOBAL float*)cd.code2;
     if (windowed)
         {
             const int span = (int)span_ll;
@@ -528,33 +551,42 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
                             i = (i >= L) ? i - L : i;
                             i = (i >= L) ? i - L : i;
                             table_c[k] = code[i];
+                            if (DATA) table2[k] = code2[i];
                         }
                 }
             else
                 {
-                    for (int k = tid; k < span; k += THREADS) table_c[k] = code[(cbase + k) % L];
+                    for (int k = tid; k < span; k += THREADS)
+                        {
+                            table_c[k] = code[(cbase + k) % L];
+                            if (DATA) table2[k] = code2[(cbase + k) % L];
+                        }
                 }
         }
     else
         {
-            for (int k = tid; k < L; k += THREADS) table_c[k] = code[k];
+            for (int k = tid; k < L; k += THREADS)
+                {
+                    table_c[k] = code[k];
+                    if (DATA) table2[k] = code2[k];
+                }
         }
     __syncthreads();
 
-    float accr[NTAPS], acci[NTAPS];
+    float accr[NACC], acci[NACC];
 #pragma unroll
-    for (int t = 0; t < NTAPS; t++) accr[t] = acci[t] = 0.0f;
+    for (int t = 0; t < NACC; t++) accr[t] = acci[t] = 0.0f;
 
     if (windowed)
-        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS, DATA>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
     else
-        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci);
+        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int t = 0; t < NTAPS; t++)
+    for (int t = 0; t < NACC; t++)
         {
             float sr, si;
             if (SC16)
@@ -569,13 +601,13 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
                 }
             if (lane == 63)
                 {
-                    lds[(wave * NTAPS + t) * 2 + 0] = sr;
-                    lds[(wave * NTAPS + t) * 2 + 1] = si;
+                    lds[(wave * NACC + t) * 2 + 0] = sr;
+                    lds[(wave * NACC + t) * 2 + 1] = si;
                 }
         }
     __syncthreads();
     float2 r = make_float2(0.f, 0.f);
-    if (tid < NTAPS)
+    if (tid < NACC)
         {
             float sr = 0.f, si = 0.f;
 #pragma unroll
@@ -583,13 +615,13 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
                 {
                     if (SC16)
                         {
-                            sr = __int_as_float(__float_as_int(sr) + __float_as_int(lds[(w * NTAPS + tid) * 2 + 0]));
-                            si = __int_as_float(__float_as_int(si) + __float_as_int(lds[(w * NTAPS + tid) * 2 + 1]));
+                            sr = __int_as_float(__float_as_int(sr) + __float_as_int(lds[(w * NACC + tid) * 2 + 0]));
+                            si = __int_as_float(__float_as_int(si) + __float_as_int(lds[(w * NACC + tid) * 2 + 1]));
                         }
                     else
                         {
-                            sr += lds[(w * NTAPS + tid) * 2 + 0];
-                            si += lds[(w * NTAPS + tid) * 2 + 1];
+                            sr += lds[(w * NACC + tid) * 2 + 0];
+                            si += lds[(w * NACC + tid) * 2 + 1];
                         }
                 }
             r = make_float2(sr, si);

@@ -16,6 +16,7 @@ struct TrkChan
     unsigned ring_len;         // 0: sample_offset is relative to iq; else iq is a gc_stream ring of ring_len samples and
                                // sample_offset an absolute sample number (the window is contiguous thanks to the mirror)
     float shifts[GC_MAX_TAPS]; // tap shifts in code samples
+    const float* code2;        // closed loop, pilot tracking: replica of the data component (prompt-only correlator); else NULL
 };
 
 enum

@@ -112,9 +112,39 @@ LOOP_RECORD_DTYPE = np.dtype([
     ("carr_phase_error_hz", np.float32), ("carr_error_filt_hz", np.float32), ("code_error_chips", np.float32),
     ("code_error_filt_chips", np.float32), ("cn0_db_hz", np.float32), ("carrier_lock_test", np.float32),
     ("sample_counter", np.uint64), ("acc_carrier_phase_rad", np.float64), ("rem_code_phase_samples", np.float64),
-    ("state", np.int32), ("valid", np.int32), ("current_prn_length_samples", np.int32), ("reserved", np.int32),
+    ("state", np.int32), ("valid", np.int32), ("current_prn_length_samples", np.int32), ("extend_count", np.int32),
+    ("accu", np.float32, (10,)), ("prompt_data", np.float32, (2,)), ("integrating", np.int32), ("reserved", np.int32),
 ], align=True)
-assert LOOP_RECORD_DTYPE.itemsize == 112 and C.sizeof(LoopConf) == 144
+
+
+class LoopSyncConf(C.Structure):
+    """gc_loop_sync_conf: symbol synchronisation, extended integration and pilot tracking of one channel."""
+    _fields_ = [
+        ("extend_correlation_symbols", C.c_int32), ("track_pilot", C.c_int32), ("symbols_per_bit", C.c_int32),
+        ("secondary_code_length", C.c_int32), ("preamble_length_symbols", C.c_int32), ("bit_sync_min_time_s", C.c_float),
+        ("pll_bw_narrow_hz", C.c_float), ("dll_bw_narrow_hz", C.c_float), ("early_late_space_narrow_chips", C.c_float),
+        ("very_early_late_space_narrow_chips", C.c_float), ("secondary_code", C.c_char * 128), ("preamble_symbols", C.c_int8 * 192),
+    ]
+
+    @classmethod
+    def make(cls, extend_correlation_symbols=1, track_pilot=False, symbols_per_bit=1, secondary_code="", preamble_symbols=(),
+            bit_sync_min_time_s=10.0, pll_bw_narrow_hz=0.0, dll_bw_narrow_hz=0.0, early_late_space_narrow_chips=0.0,
+            very_early_late_space_narrow_chips=0.0):
+        y = cls()
+        y.extend_correlation_symbols, y.track_pilot, y.symbols_per_bit = int(extend_correlation_symbols), int(bool(track_pilot)), int(symbols_per_bit)
+        y.secondary_code_length, y.preamble_length_symbols = len(secondary_code), len(preamble_symbols)
+        y.bit_sync_min_time_s = bit_sync_min_time_s
+        y.pll_bw_narrow_hz, y.dll_bw_narrow_hz = pll_bw_narrow_hz, dll_bw_narrow_hz
+        y.early_late_space_narrow_chips, y.very_early_late_space_narrow_chips = early_late_space_narrow_chips, very_early_late_space_narrow_chips
+        if len(secondary_code) > 128 or len(preamble_symbols) > 192:
+            raise ValueError("secondary code / preamble too long")
+        y.secondary_code = secondary_code.encode()
+        for i, v in enumerate(preamble_symbols):
+            y.preamble_symbols[i] = int(v)
+        return y
+
+
+assert LOOP_RECORD_DTYPE.itemsize == 168 and C.sizeof(LoopConf) == 144 and C.sizeof(LoopSyncConf) == 360
 
 
 # every symbol include/gnsscorr.h declares: name -> (restype, argtypes)
@@ -171,6 +201,7 @@ API = {
     "gc_trk_loop_create": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gc_trk_loop_destroy": (C.c_int, [_vp]),
     "gc_trk_loop_set_input_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
+    "gc_trk_loop_set_sync": (C.c_int, [_vp, C.c_int, C.POINTER(LoopSyncConf), _fp, C.c_int]),
     "gc_trk_loop_start": (C.c_int, [_vp, C.c_int, C.POINTER(LoopConf), _fp, C.c_int]),
     "gc_trk_loop_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "gc_trk_loop_run": (C.c_int, [_vp, C.c_int, _vp]),
@@ -608,6 +639,18 @@ class TrackingLoop:
 
     def set_input_stream(self, ch, stream):
         _check(load_library().gc_trk_loop_set_input_stream(self._h, ch, stream._h))
+
+    def set_sync(self, ch, sync, data_code=None):
+        """Installs (or, with sync=None, removes) the LoopSyncConf of a channel; data_code is the data component's
+        replica for pilot tracking.  Takes effect at the next start()."""
+        if sync is None:
+            _check(load_library().gc_trk_loop_set_sync(self._h, ch, None, None, 0))
+            return
+        if data_code is None:
+            _check(load_library().gc_trk_loop_set_sync(self._h, ch, C.byref(sync), None, 0))
+        else:
+            data_code = np.ascontiguousarray(data_code, np.float32)
+            _check(load_library().gc_trk_loop_set_sync(self._h, ch, C.byref(sync), _f32p(data_code), data_code.size))
 
     def start(self, ch, conf, code):
         code = np.ascontiguousarray(code, np.float32)

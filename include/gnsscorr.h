@@ -299,11 +299,35 @@ typedef struct
     uint64_t sample_counter;     /* Tracking_sample_counter after this epoch */
     double acc_carrier_phase_rad;
     double rem_code_phase_samples;
-    int32_t state;               /* 2 = tracking, 0 = standby (after loss of lock), 1 = pull-in pending */
+    int32_t state;               /* d_state after this code period: 0 = standby (after loss of lock), 1 = pull-in pending,
+                                  * 2 = wide tracking / symbol synchronisation, 3 = extended integration, 4 = narrow tracking */
     int32_t valid;               /* Flag_valid_symbol_output */
     int32_t current_prn_length_samples;
+    int32_t extend_count;        /* d_extend_correlation_symbols_count when log_data ran (scale factor of the dump, :1179-1191) */
+    float accu[10];              /* d_VE/E/P/L/VL_accu as log_data sees them (before the reset that follows a loop update) */
+    float prompt_data[2];        /* d_Prompt_Data (pilot tracking: prompt of the data component), else the prompt tap */
+    int32_t integrating;         /* 1: the period only accumulated (state 3, log_data(true)); 0: the loop filters ran */
     int32_t reserved;
 } gc_loop_record;
+
+/* Symbol synchronisation, extended integration and pilot tracking (dll_pll_veml_tracking.cc:1601-1896): what the block's
+ * constructor derives from the signal (:113-336) plus the Dll_Pll_Conf fields of the narrow stage.  Without it a channel
+ * stays in state 2 (1 code period per loop update, data component), which is what the block does for a signal whose
+ * telemetry preamble is never found. */
+typedef struct
+{
+    int32_t extend_correlation_symbols;   /* Dll_Pll_Conf::extend_correlation_symbols (>= 1; 1 = no extension) */
+    int32_t track_pilot;                  /* Dll_Pll_Conf::track_pilot: `code` of gc_trk_loop_start is the pilot replica,
+                                           * data_code the data component's; four-quadrant PLL once the secondary code is locked */
+    int32_t symbols_per_bit;              /* d_symbols_per_bit */
+    int32_t secondary_code_length;        /* d_secondary_code_length, 0 = no secondary code (<= 128) */
+    int32_t preamble_length_symbols;      /* d_preamble_length_symbols, 0 = none (<= 192) */
+    float bit_sync_min_time_s;            /* tracking time before the preamble search starts: 10 in the reference (:1648) */
+    float pll_bw_narrow_hz, dll_bw_narrow_hz;
+    float early_late_space_narrow_chips, very_early_late_space_narrow_chips;
+    char secondary_code[128];             /* '0' / '1', like the reference's secondary-code strings */
+    int8_t preamble_symbols[192];         /* +1 / -1 (d_preambles_symbols) */
+} gc_loop_sync_conf;
 
 typedef struct gc_trk_loop gc_trk_loop;
 gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, gc_trk_loop** out);
@@ -319,6 +343,10 @@ gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, 
  * launch are marked invalid, state unchanged), so "push a block, run" is the whole host loop.
  * gc_trk_loop_run reports GC_ERR_STATE when a channel has fallen behind the ring's oldest sample. */
 gc_status gc_trk_loop_set_input_stream(gc_trk_loop* l, int ch, gc_stream* s);
+/* Installs (sync != NULL) or removes the synchronisation / extension description of channel `ch`; it takes effect at the
+ * next gc_trk_loop_start.  data_code (data_code_length floats, same length as the tracking replica) is required with
+ * track_pilot and ignored otherwise.  All channels of one engine share the pilot mode. */
+gc_status gc_trk_loop_set_sync(gc_trk_loop* l, int ch, const gc_loop_sync_conf* sync, const float* data_code, int data_code_length);
 /* dll_pll_veml_tracking::start_tracking (:549-747): uploads the replica (code_length_chips *
  * code_samples_per_chip floats), sets the taps from the spacings and initialises the loop. */
 gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, const float* code, int code_length);

@@ -1,0 +1,257 @@
+"""GPU parity of the closed-loop engine's symbol synchronisation, extended integration and pilot tracking
+(states 2 -> 3 -> 4 of dll_pll_veml_tracking::general_work, :1601-1896) against the Python restatement of the
+same state machine on the CPU oracle correlator (tests/closed_loop_ref.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Galileo OS SIS ICD, CS25_1 (the reference holds it as GALILEO_E1_C_SECONDARY_CODE, Galileo_E1.h)
+E1C_SECONDARY = "0011100000001010110110010"
+# BeiDou ICD B1I Neumann-Hoffman code (BEIDOU_B1I_SECONDARY_CODE_STR, Beidou_B1I.h)
+NH20 = "00000100110101001110"
+GPS_PREAMBLE_BITS = [1, 0, 0, 0, 1, 0, 1, 1]  # GPS_PREAMBLE, GPS_L1_CA.h
+
+
+def _conf(gnsscorr, **kw):
+    c = gnsscorr.LoopConf()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _sync(gnsscorr, y):
+    return gnsscorr.LoopSyncConf.make(**y)
+
+
+def _stream(components, fs, n, doppler, delay, cn0, seed, chip_rate_samples, carrier_hz=1575.42e6):
+    """components: list of (replica[L] at `chip_rate_samples` code samples per second, symbols per code period (+-1),
+    amplitude sign).  Code period p of the stream carries symbols[p]; period 0 is the partial one before `delay`, and the
+    pull-in of the loop skips period 1 as well, so tracked period k is stream period k + 2."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    i = np.arange(n)
+    L = components[0][0].size
+    rate = chip_rate_samples * (1 + doppler / carrier_hz) / fs
+    ph = (L - delay * chip_rate_samples / fs) + i * rate
+    k = np.floor(ph).astype(np.int64)
+    period = k // L
+    chip = k % L
+    amp = np.sqrt(10 ** (cn0 / 10) / fs)
+    s = np.zeros(n)
+    for rep, sym, sign in components:
+        sym = np.asarray(sym, np.float64)
+        s += sign * rep[chip] * sym[period % sym.size]
+    x = amp * s * np.exp(1j * (2 * np.pi * doppler * i / fs + 0.7)) + (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.sqrt(0.5)
+    return x.astype(np.complex64)
+
+
+def _compare(rec, ref, n_taps, tol=3e-3):
+    assert len(ref) == len(rec)
+    pi = n_taps // 2
+    for k in range(len(ref)):
+        r, g = ref[k], rec[k]
+        assert int(g["state"]) == r["state"], (k, int(g["state"]), r["state"])
+        assert int(g["sample_counter"]) == r["sample_counter"], k
+        assert int(g["valid"]) == r["valid"] and int(g["integrating"]) == r["integrating"] and int(g["extend_count"]) == r["ext_count"], k
+        scale = abs(r["corr"][pi]) + 1e-9
+        gc = g["corr"][0:2 * n_taps:2] + 1j * g["corr"][1:2 * n_taps:2]
+        assert np.max(np.abs(gc - r["corr"])) <= tol * scale, k
+        gd = g["prompt_data"][0] + 1j * g["prompt_data"][1]
+        assert abs(gd - r["prompt_data"]) <= tol * max(scale, abs(r["prompt_data"])), k
+        ga = g["accu"][0::2] + 1j * g["accu"][1::2]
+        assert np.max(np.abs(ga - r["accu"])) <= tol * max(scale, np.max(np.abs(r["accu"]))), k
+        assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.05, k
+        assert abs(float(g["code_error_chips"]) - r["cerr"]) < 3e-3, k
+        assert abs(float(g["cn0_db_hz"]) - r["cn0"]) < 0.05 and abs(float(g["carrier_lock_test"]) - r["lock_test"]) < 2e-3, k
+
+
+GAL = dict(fs_in=4e6, signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=1.023e6, code_period_s=0.004, carrier_lock_th=0.85,
+    code_length_chips=4092, code_samples_per_chip=2, vector_length=16000, pull_in_time_s=0, veml=1, pll_filter_order=3, dll_filter_order=2,
+    enable_fll_pull_in=0, enable_fll_steady_state=0, cn0_samples=10, cn0_min=25, max_lock_fail=50, pll_bw_hz=15.0, dll_bw_hz=0.75, fll_bw_hz=10.0,
+    early_late_space_chips=0.15, very_early_late_space_chips=0.6, acq_samplestamp_samples=0, sample_counter=0)
+GPS = dict(fs_in=4e6, signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=1.023e6, code_period_s=0.001, carrier_lock_th=0.85,
+    code_length_chips=1023, code_samples_per_chip=1, vector_length=4000, pull_in_time_s=0, veml=0, pll_filter_order=3, dll_filter_order=2,
+    enable_fll_pull_in=0, enable_fll_steady_state=0, cn0_samples=20, cn0_min=25, max_lock_fail=50, pll_bw_hz=40.0, dll_bw_hz=2.0, fll_bw_hz=35.0,
+    early_late_space_chips=0.5, very_early_late_space_chips=0.0, acq_samplestamp_samples=0, sample_counter=0)
+
+
+@pytest.mark.parametrize("ext", [1, 3])
+def test_galileo_e1_pilot_tracking_with_secondary_code_and_extension(gctx, oracle, ext):
+    """track_pilot: the E1-C replica drives the loop, the secondary code CS25 is found on the prompt signs
+    (acquire_secondary), the loop then integrates `ext` code periods coherently with the secondary code wiped off, the
+    narrow bandwidths / spacings and the four-quadrant PLL; the E1-B prompt (d_Prompt_Data) carries the data symbols."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    z = np.load(os.path.join(G, "galileo_e1_codes.npz"))
+    e1b, e1c = oracle.galileo_e1_sinboc11(z["e1b"][10]), oracle.galileo_e1_sinboc11(z["e1c"][10])
+    fs, n_ep = 4e6, 25 + 6 + 12 * max(ext, 2)
+    rng = np.random.Generator(np.random.PCG64(5))
+    data = rng.integers(0, 2, 400) * 2 - 1
+    # the pilot's secondary code starts 7 code periods into the stream; '0' <-> +1
+    sec = np.roll(np.array([1.0 if c == "0" else -1.0 for c in E1C_SECONDARY]), 7)
+    doppler, delay = 2210.0, 3456.0
+    x = _stream([(e1b, data, 1.0), (e1c, sec, 1.0)], fs, 16000 * (n_ep + 3), doppler, delay, 48.0, 77, 2.046e6)
+    conf = dict(GAL, acq_delay_samples=delay, acq_doppler_hz=doppler - 1.0, pll_bw_hz=25.0)
+    y = dict(extend_correlation_symbols=ext, track_pilot=True, symbols_per_bit=1, secondary_code=E1C_SECONDARY, pll_bw_narrow_hz=10.0,
+        dll_bw_narrow_hz=0.5, early_late_space_narrow_chips=0.1, very_early_late_space_narrow_chips=0.5)
+    ref = ref_run(oracle, x, e1c, conf, n_ep, sync=y, data_code=e1b)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 8184)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.set_sync(0, _sync(gnsscorr, y), e1b)
+    loop.start(0, _conf(gnsscorr, **conf), e1c)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    _compare(rec, ref, 5)
+    states = rec["state"]
+    # secondary code locked at the end of the first complete CS25 (stream periods 7..31)
+    first = int(np.argmax(states != 2))
+    assert states[first] == (3 if ext > 1 else 4) and first == 7 + 25 - 1 - 2
+    if ext > 1:
+        tail = states[first:]
+        assert set(tail.tolist()) == {3, 4} and np.all(rec["integrating"][first + 1:][tail[:-1] == 3] == 1)
+        # loop updates every `ext` periods: the accumulated prompt is ~ext times a single one, secondary code wiped off
+        upd = np.nonzero((rec["integrating"] == 0) & (np.arange(n_ep) > first))[0]
+        assert np.all(np.diff(upd) == ext)
+        acc = np.hypot(rec["accu"][upd, 4], rec["accu"][upd, 5])
+        one = np.hypot(rec["corr"][upd, 4], rec["corr"][upd, 5])
+        assert np.all(acc > 0.9 * ext * one) and np.all(acc < 1.1 * ext * one)
+    # the data prompt follows the E1-B symbols (the Costas loop of state 2 locked upright for this seed; an inverted lock
+    # costs the four-quadrant PLL a half-cycle transient first)
+    got = np.sign(rec["prompt_data"][first:, 0])
+    want = data[(np.arange(first, n_ep) + 2) % data.size]
+    assert abs(np.sum(got * want)) == got.size
+    assert abs(rec["carrier_doppler_hz"][-5:].mean() - doppler) < 3.0
+
+
+@pytest.mark.parametrize("ext", [1, 5])
+def test_secondary_code_without_pilot_keeps_the_costas_loop(gctx, oracle, ext):
+    """BeiDou B1I shape: NH20 on the data component itself, no pilot: state 4 (or 3/4 with extension) accumulates with
+    the NH sign, the PLL stays two-quadrant (d_cloop, :1116-1124)."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    code = oracle.gps_l1_ca_code(9).astype(np.float32)
+    fs, n_ep = 4e6, 20 + 4 + 10 * ext
+    nh = np.roll(np.array([1.0 if c == "0" else -1.0 for c in NH20]), 3)
+    x = _stream([(code, nh, 1.0)], fs, 4000 * (n_ep + 3), -777.0, 2222.0, 47.0, 12, 1.023e6)
+    conf = dict(GPS, acq_delay_samples=2222.0, acq_doppler_hz=-770.0)
+    y = dict(extend_correlation_symbols=ext, track_pilot=False, symbols_per_bit=20, secondary_code=NH20, pll_bw_narrow_hz=20.0,
+        dll_bw_narrow_hz=1.5, early_late_space_narrow_chips=0.3)
+    ref = ref_run(oracle, x, code, conf, n_ep, sync=y)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.set_sync(0, _sync(gnsscorr, y))
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    _compare(rec, ref, 3)
+    first = int(np.argmax(rec["state"] != 2))
+    assert first == 3 + 20 - 1 - 2 and rec["state"][-1] in (3, 4)
+    # without a pilot the data prompt is the prompt tap itself
+    assert np.array_equal(rec["prompt_data"], rec["corr"][:, 2:4])
+
+
+@pytest.mark.parametrize("polarity", [-1.0, 1.0])
+def test_gps_preamble_bit_synchronisation(gctx, oracle, polarity):
+    """GPS L1 C/A shape: no secondary code, 20 symbols per bit; after bit_sync_min_time_s the signs of the last 160
+    prompts are compared with the telemetry preamble (:1645-1685); the period that completes it switches to the
+    extended integrator, aligned with the bit edges.  Only the upright preamble counts (corr_value == +length): when the
+    Costas loop has locked half a cycle off (the other polarity of the same stream) the block never leaves state 2."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    code = oracle.gps_l1_ca_code(17).astype(np.float32)
+    fs, ext = 4e6, 4
+    rng = np.random.Generator(np.random.PCG64(41))
+    bits = list(rng.integers(0, 2, 6)) + GPS_PREAMBLE_BITS + list(rng.integers(0, 2, 4))
+    # bit edges 5 code periods into the stream
+    sym = np.roll(np.repeat(np.array(bits) * 2.0 - 1.0, 20), 5)
+    n_ep = 5 + 20 * (6 + 8) + 30
+    x = _stream([(code, sym, polarity)], fs, 4000 * (n_ep + 3), 1500.0, 100.0, 50.0, 8, 1.023e6)
+    conf = dict(GPS, acq_delay_samples=100.0, acq_doppler_hz=1504.0)
+    pre = [1 if b else -1 for b in GPS_PREAMBLE_BITS for _ in range(20)]
+    y = dict(extend_correlation_symbols=ext, track_pilot=False, symbols_per_bit=20, preamble_symbols=pre, bit_sync_min_time_s=0.03,
+        pll_bw_narrow_hz=20.0, dll_bw_narrow_hz=1.0, early_late_space_narrow_chips=0.5)
+    ref = ref_run(oracle, x, code, conf, n_ep, sync=y)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.set_sync(0, _sync(gnsscorr, y))
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    _compare(rec, ref, 3)
+    if polarity > 0:
+        assert np.all(rec["state"] == 2)  # this seed's Costas lock shows the stream inverted
+        return
+    first = int(np.argmax(rec["state"] != 2))
+    # the preamble's last symbol is stream period 5 + 20 * 14 - 1
+    assert first == 5 + 20 * 14 - 1 - 2 and rec["state"][first] == 3
+    assert np.sign(rec["corr"][first, 2]) == 1.0
+    assert set(rec["state"][first:].tolist()) == {3, 4}
+
+
+def test_single_symbol_signal_goes_straight_to_narrow_tracking(gctx, oracle):
+    """symbols_per_bit == 1 and no secondary code (Galileo E1-B alone): the first loop update already hands over to state 4
+    (:1686-1689), which without extension is the same arithmetic as state 2."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    code = oracle.gps_l1_ca_code(3).astype(np.float32)
+    fs, n_ep = 4e6, 60
+    x = _stream([(code, [1.0], 1.0)], fs, 4000 * (n_ep + 3), 300.0, 700.0, 45.0, 3, 1.023e6)
+    conf = dict(GPS, acq_delay_samples=700.0, acq_doppler_hz=296.0)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    out = []
+    for y in (dict(extend_correlation_symbols=1, symbols_per_bit=1), None):
+        loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+        loop.set_input_dev(0, d.data_ptr(), x.size)
+        if y:
+            loop.set_sync(0, _sync(gnsscorr, y))
+        loop.start(0, _conf(gnsscorr, **conf), code)
+        out.append(loop.run(n_ep)[0])
+        loop.close()
+    a, b = out
+    assert np.all(a["state"] == 4) and np.all(b["state"] == 2)
+    for f in ("corr", "sample_counter", "carrier_doppler_hz", "code_freq_chips", "cn0_db_hz", "acc_carrier_phase_rad", "valid"):
+        assert np.array_equal(a[f], b[f]), f
+    _compare(a, ref_run(oracle, x, code, conf, n_ep, sync=dict(extend_correlation_symbols=1, symbols_per_bit=1)), 3)
+
+
+def test_sync_argument_checks(gctx, oracle):
+    import gnsscorr
+    import torch
+    code = oracle.gps_l1_ca_code(3).astype(np.float32)
+    d = torch.zeros(2 * 4000 * 4, dtype=torch.float32, device="cuda")
+    loop = gnsscorr.TrackingLoop(gctx, 2, 1023)
+    for ch in range(2):
+        loop.set_input_dev(ch, d.data_ptr(), 4000 * 4)
+    conf = _conf(gnsscorr, **dict(GPS, acq_delay_samples=0.0, acq_doppler_hz=0.0))
+    with pytest.raises(gnsscorr.GnsscorrError, match="data component"):
+        loop.set_sync(0, _sync(gnsscorr, dict(track_pilot=True)))
+    bad = _sync(gnsscorr, dict(secondary_code="0101"))
+    bad.secondary_code = b"01x1"
+    with pytest.raises(gnsscorr.GnsscorrError, match="not '0' or '1'"):
+        loop.set_sync(0, bad)
+    with pytest.raises(gnsscorr.GnsscorrError, match="extend_correlation_symbols"):
+        loop.set_sync(0, _sync(gnsscorr, dict(extend_correlation_symbols=0)))
+    # the data replica must be as long as the tracking replica
+    loop.set_sync(0, _sync(gnsscorr, dict(track_pilot=True)), code[:1000])
+    with pytest.raises(gnsscorr.GnsscorrError, match="data replica"):
+        loop.start(0, conf, code)
+    # one engine, one pilot mode
+    loop.set_sync(0, _sync(gnsscorr, dict(track_pilot=True)), code)
+    loop.start(0, conf, code)
+    with pytest.raises(gnsscorr.GnsscorrError, match="pilot mode"):
+        loop.start(1, conf, code)
+    loop.set_sync(1, _sync(gnsscorr, dict(track_pilot=True)), code)
+    loop.start(1, conf, code)
+    rec = loop.run(2)
+    assert rec.shape == (2, 2)
+    loop.close()

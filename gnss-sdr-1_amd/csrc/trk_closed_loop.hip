@@ -614,7 +614,7 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
                             s.sample_counter += samples_offset;
                             s.pos += samples_offset;
                         }
-                    if (s.state != 2 || s.pos + c.vector_length > limit) go = 0;  // standby, or the input block is exhausted
+                    if (s.state < 2 || s.pos + c.vector_length > limit) go = 0;  // standby, or the input block is exhausted
                     if (go)
                         {
                             // do_correlation_step (:886-897): the scalars are narrowed to float exactly there

@@ -57,7 +57,22 @@ public:
         trk_param.pull_in_time_s = static_cast<unsigned int>(configuration->property(role + ".pull_in_time_s", 2.0f));
         trk_param.early_late_space_chips = configuration->property(role + ".early_late_space_chips", gal ? 0.15f : 0.5f);
         trk_param.early_late_space_narrow_chips = configuration->property(role + ".early_late_space_narrow_chips", gal ? 0.15f : 0.5f);
-        trk_param.extend_correlation_symbols = std::max(1, configuration->property(role + ".extend_correlation_symbols", 1));
+        // extend_correlation_symbols / track_pilot rules of the reference adapters (gps_l1_ca_dll_pll_tracking.cc:140-165,
+        // galileo_e1_dll_pll_veml_tracking.cc:134-159, beidou_b1i_dll_pll_tracking.cc:128-151)
+        int extend_correlation_symbols = configuration->property(role + ".extend_correlation_symbols", 1);
+        bool track_pilot = configuration->property(role + ".track_pilot", false);
+        if (extend_correlation_symbols < 1) extend_correlation_symbols = 1;
+        if (gal)
+            {
+                // extended integration needs the pilot: the data component has a symbol transition every code period
+                if (!track_pilot && extend_correlation_symbols > 1) extend_correlation_symbols = 1;
+            }
+        else
+            {
+                if (extend_correlation_symbols > 20) extend_correlation_symbols = 20;  // one telemetry bit
+                track_pilot = false;  // GPS L1 C/A and BeiDou B1I have no pilot component
+            }
+        trk_param.extend_correlation_symbols = extend_correlation_symbols;
         if (gal)
             {
                 trk_param.very_early_late_space_chips = configuration->property(role + ".very_early_late_space_chips", 0.6f);
@@ -82,7 +97,7 @@ public:
                 trk_param.system = 'G';
                 std::memcpy(trk_param.signal, "1C", 3);
             }
-        trk_param.track_pilot = false;
+        trk_param.track_pilot = track_pilot;
         trk_param.cn0_samples = configuration->property(role + ".cn0_samples", 20);
         trk_param.cn0_min = configuration->property(role + ".cn0_min", SIG == TrkSignal::GPS_L1_CA ? 30 : 25);
         trk_param.max_lock_fail = configuration->property(role + ".max_lock_fail", 50);

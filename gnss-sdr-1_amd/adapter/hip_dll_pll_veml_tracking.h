@@ -5,15 +5,16 @@
  * hot path (GPS L1 C/A "1C", Galileo E1 "1B", BeiDou B1I "B1"), with the correlations done by
  * Hip_Multicorrelator_Real_Codes (libgnsscorr.so, MI355X).
  *
- * Mirrored: constructor set-up of taps/shifts (dll_pll_veml_tracking.cc:330-440), start_tracking (:549-747),
- * the state machine of general_work for states 0 (standby), 1 (pull-in) and 2 (wide tracking) (:1544-1773),
- * do_correlation_step (:886-911), run_dll_pll (:914-973), update_tracking_vars (:998-1070) incl. the
+ * Mirrored: constructor set-up of taps/shifts and of the per-signal synchronisation data (dll_pll_veml_tracking.cc:113-440),
+ * start_tracking (:549-747), the whole state machine of general_work (:1544-1907): standby (0), pull-in (1), wide
+ * tracking with secondary-code lock (acquire_secondary, :800-836) or telemetry-preamble bit synchronisation (2),
+ * extended coherent integration (3) and narrow tracking (4) with save_correlation_results (:1072-1125);
+ * do_correlation_step (:886-911) incl. the data-component prompt correlator of pilot tracking (Galileo E1-C drives
+ * the loop, E1-B is demodulated), run_dll_pll (:914-973), update_tracking_vars (:998-1070) incl. the
  * high-dynamics rate smoother, cn0_and_tracking_lock_status (:839-878), the Gnss_Synchro record written
- * per epoch (:1730-1770, :1898-1906).
- * Not mirrored (outside the correlator hot path): telemetry preamble / secondary-code synchronisation and
- * the extended-integration states 3/4 that it enables (the block stays in state 2), the .mat conversion of
- * the dump, the telemetry fault message handler, the pilot (E1-C) component.  The binary dump itself
- * (log_data, :1128-1250) is written in the reference's record layout.
+ * per epoch (:1693-1725, :1898-1906).
+ * Not mirrored (outside the correlator hot path): the .mat conversion of the dump and the telemetry fault message
+ * handler.  The binary dump itself (log_data, :1128-1250) is written in the reference's record layout.
  *
  * general_work(noutput, ninput_items, input_items, output_items) becomes
  * work(in, ninput_items, out): returns the number of input items consumed (consume_each) and sets
@@ -45,10 +46,12 @@ public:
                 d_signal_carrier_freq = 1575.42e6;  // GPS_L1_FREQ_HZ
                 d_code_period = 0.001;
                 d_code_chip_rate = 1.023e6;
+                d_symbols_per_bit = 20;  // GPS_CA_TELEMETRY_SYMBOLS_PER_BIT
                 d_correlation_length_ms = 1;
                 d_code_samples_per_chip = 1;
                 d_code_length_chips = 1023;
-                trk_parameters.track_pilot = false;
+                trk_parameters.track_pilot = false;  // no pilot component, no secondary code
+                set_preamble({1, 0, 0, 0, 1, 0, 1, 1}, 20);  // GPS_PREAMBLE, one entry per 1 ms symbol (:129-150)
             }
         else if (trk_parameters.system == 'E' && signal_type == "1B")
             {
@@ -59,7 +62,12 @@ public:
                 d_correlation_length_ms = 4;
                 d_code_samples_per_chip = 2;  // sinBOC(1,1) replica, 2 samples per chip
                 d_veml = true;
-                trk_parameters.track_pilot = false;  // E1-C pilot tracking is not mirrored
+                d_symbols_per_bit = 1;
+                if (trk_parameters.track_pilot)
+                    {
+                        d_secondary = true;
+                        d_secondary_code_string = "0011100000001010110110010";  // GALILEO_E1_C_SECONDARY_CODE (OS SIS ICD, CS25_1)
+                    }
             }
         else if (trk_parameters.system == 'C' && signal_type == "B1")
             {
@@ -69,7 +77,24 @@ public:
                 d_code_length_chips = 2046;
                 d_correlation_length_ms = 1;
                 d_code_samples_per_chip = 1;
+                d_symbols_per_bit = 20;  // BEIDOU_B1I_TELEMETRY_SYMBOLS_PER_BIT
+                d_secondary = true;
+                d_secondary_code_string = "00000100110101001110";  // BEIDOU_B1I_SECONDARY_CODE_STR (NH20)
                 trk_parameters.track_pilot = false;
+            }
+        if (trk_parameters.extend_correlation_symbols > 1)
+            d_enable_extended_integration = true;
+        else
+            {
+                d_enable_extended_integration = false;
+                trk_parameters.extend_correlation_symbols = 1;
+            }
+        if (trk_parameters.track_pilot)
+            {
+                // extra prompt correlator for the data component, slaved to the pilot prompt (:404-416)
+                correlator_data_cpu.init(2 * trk_parameters.vector_length, 1);
+                correlator_data_cpu.set_high_dynamics_resampler(trk_parameters.high_dyn);
+                d_data_code.assign(2 * d_code_length_chips, 0.0f);
             }
         d_code_loop_filter = Tracking_loop_filter(d_code_period, trk_parameters.dll_bw_hz, trk_parameters.dll_filter_order, false);
         d_carrier_loop_filter.set_params(trk_parameters.fll_bw_hz, trk_parameters.pll_bw_hz, trk_parameters.pll_filter_order);
@@ -120,10 +145,31 @@ public:
         else if (trk_parameters.system == 'E')
             {
                 char sig[3] = "1B";
-                gc_galileo_e1_code_gen_sinboc11_float(d_tracking_code.data(), sig, d_acquisition_gnss_synchro->PRN);
+                if (trk_parameters.track_pilot)
+                    {
+                        char pilot_signal[3] = "1C";
+                        gc_galileo_e1_code_gen_sinboc11_float(d_tracking_code.data(), pilot_signal, d_acquisition_gnss_synchro->PRN);
+                        gc_galileo_e1_code_gen_sinboc11_float(d_data_code.data(), sig, d_acquisition_gnss_synchro->PRN);
+                        d_Prompt_Data = gr_complex(0.0, 0.0);
+                        // the data correlator's only tap IS the prompt shift of the main correlator (pointer, not copy)
+                        correlator_data_cpu.set_local_code_and_taps(d_code_samples_per_chip * d_code_length_chips, d_data_code.data(),
+                            &d_local_code_shift_chips[2]);
+                    }
+                else
+                    gc_galileo_e1_code_gen_sinboc11_float(d_tracking_code.data(), sig, d_acquisition_gnss_synchro->PRN);
             }
         else
-            gc_beidou_b1i_code_gen_float(d_tracking_code.data(), static_cast<int32_t>(d_acquisition_gnss_synchro->PRN), 0);
+            {
+                gc_beidou_b1i_code_gen_float(d_tracking_code.data(), static_cast<int32_t>(d_acquisition_gnss_synchro->PRN), 0);
+                if (d_acquisition_gnss_synchro->PRN > 0 and d_acquisition_gnss_synchro->PRN < 6)
+                    {
+                        // GEO satellites broadcast D2: 2 symbols per bit, no NH code, 11-bit preamble (:631-665)
+                        d_symbols_per_bit = 2;
+                        d_secondary = false;
+                        d_secondary_code_string.clear();
+                        set_preamble({1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 0}, 2);
+                    }
+            }
         multicorrelator_cpu.set_local_code_and_taps(d_code_samples_per_chip * d_code_length_chips, d_tracking_code.data(), d_local_code_shift_chips.data());
         std::fill(d_correlator_outs.begin(), d_correlator_outs.end(), gr_complex(0.0, 0.0));
         d_carrier_lock_fail_counter = 0;
@@ -141,6 +187,7 @@ public:
         d_state = 1;  // pull-in
         d_cloop = true;
         d_pull_in_transitory = true;
+        d_Prompt_circular_buffer.clear();
     }
 
     void stop_tracking()
@@ -152,7 +199,7 @@ public:
     //! forecast (:507-514): the scheduler calls work() with at least this many items
     int required_input_items() const { return static_cast<int>(trk_parameters.vector_length) * 2; }
 
-    /*! general_work (:1544-1907), states 0..2 */
+    /*! general_work (:1544-1907) */
     int work(const gr_complex* in, int ninput_items, Gnss_Synchro* out, int* produced)
     {
         std::lock_guard<std::mutex> l(d_setlock);
@@ -185,7 +232,7 @@ public:
                     d_sample_counter += samples_offset;
                     return samples_offset;
                 }
-            case 2:  // wide tracking
+            case 2:  // wide tracking and symbol synchronisation (:1601-1773)
                 {
                     do_correlation_step(in);
                     if (d_veml)
@@ -200,22 +247,103 @@ public:
                         {
                             clear_tracking_vars();
                             d_state = 0;  // loss of lock
+                            break;
+                        }
+                    run_dll_pll();
+                    update_tracking_vars();
+                    log_data(false);
+                    const gr_complex prompt = d_correlator_outs[d_veml ? 2 : 1];
+                    bool next_state = false;
+                    if (d_secondary)
+                        {
+                            d_Prompt_circular_buffer.push_back(prompt);
+                            if (d_Prompt_circular_buffer.size() > d_secondary_code_string.size()) d_Prompt_circular_buffer.pop_front();
+                            if (d_Prompt_circular_buffer.size() == d_secondary_code_string.size()) next_state = acquire_secondary();
+                        }
+                    else if (d_symbols_per_bit > 1)
+                        {
+                            // no secondary code: look for the telemetry preamble on the symbol signs, after 10 s of tracking
+                            float current_tracking_time_s = static_cast<float>(d_sample_counter - d_acq_sample_stamp) / trk_parameters.fs_in;
+                            if (current_tracking_time_s > d_bit_sync_min_time_s)
+                                {
+                                    d_symbol_history.push_back(prompt.real());
+                                    if (d_symbol_history.size() > d_preambles_symbols.size()) d_symbol_history.pop_front();
+                                    int32_t corr_value = 0;
+                                    if (d_symbol_history.size() == d_preambles_symbols.size())
+                                        {
+                                            for (size_t i = 0; i < d_symbol_history.size(); i++)
+                                                corr_value += d_symbol_history[i] < 0.0 ? -d_preambles_symbols[i] : d_preambles_symbols[i];
+                                        }
+                                    next_state = !d_preambles_symbols.empty() && corr_value == static_cast<int32_t>(d_preambles_symbols.size());
+                                }
                         }
                     else
+                        next_state = true;
+                    fill_synchro(current_synchro_data);
+                    if (next_state)
                         {
-                            run_dll_pll();
-                            update_tracking_vars();
-                            log_data();
-                            // tracking results for the telemetry decoder (:1730-1770)
-                            current_synchro_data.Prompt_I = static_cast<double>(d_P_accu.real());
-                            current_synchro_data.Prompt_Q = static_cast<double>(d_P_accu.imag());
-                            current_synchro_data.Code_phase_samples = d_rem_code_phase_samples;
-                            current_synchro_data.Carrier_phase_rads = d_acc_carrier_phase_rad;
-                            current_synchro_data.Carrier_Doppler_hz = d_carrier_doppler_hz;
-                            current_synchro_data.CN0_dB_hz = d_CN0_SNV_dB_Hz;
-                            current_synchro_data.correlation_length_ms = d_correlation_length_ms;
-                            current_synchro_data.Flag_valid_symbol_output = true;
+                            reset_accumulators();
+                            d_Prompt_circular_buffer.clear();
+                            d_current_symbol = 0;
+                            if (d_enable_extended_integration)
+                                {
+                                    d_extend_correlation_symbols_count = 0;
+                                    d_current_correlation_time_s = static_cast<float>(trk_parameters.extend_correlation_symbols) * static_cast<float>(d_code_period);
+                                    d_state = 3;
+                                    // narrow loop bandwidths and tap spacings (:1751-1766)
+                                    d_code_loop_filter.set_update_interval(d_current_correlation_time_s);
+                                    d_code_loop_filter.set_noise_bandwidth(trk_parameters.dll_bw_narrow_hz);
+                                    d_carrier_loop_filter.set_params(trk_parameters.fll_bw_hz, trk_parameters.pll_bw_narrow_hz, trk_parameters.pll_filter_order);
+                                    const float spc = static_cast<float>(d_code_samples_per_chip);
+                                    if (d_veml)
+                                        {
+                                            d_local_code_shift_chips[0] = -trk_parameters.very_early_late_space_narrow_chips * spc;
+                                            d_local_code_shift_chips[1] = -trk_parameters.early_late_space_narrow_chips * spc;
+                                            d_local_code_shift_chips[3] = trk_parameters.early_late_space_narrow_chips * spc;
+                                            d_local_code_shift_chips[4] = trk_parameters.very_early_late_space_narrow_chips * spc;
+                                        }
+                                    else
+                                        {
+                                            d_local_code_shift_chips[0] = -trk_parameters.early_late_space_narrow_chips * spc;
+                                            d_local_code_shift_chips[2] = trk_parameters.early_late_space_narrow_chips * spc;
+                                        }
+                                }
+                            else
+                                d_state = 4;
                         }
+                    break;
+                }
+            case 3:  // coherent integration (:1774-1826): accumulate, no loop update
+                {
+                    do_correlation_step(in);
+                    update_tracking_vars();
+                    save_correlation_results();
+                    fill_synchro(current_synchro_data);
+                    d_extend_correlation_symbols_count++;
+                    if (d_extend_correlation_symbols_count == (trk_parameters.extend_correlation_symbols - 1))
+                        {
+                            d_extend_correlation_symbols_count = 0;
+                            d_state = 4;
+                        }
+                    log_data(true);
+                    break;
+                }
+            case 4:  // narrow tracking (:1827-1896): last period of the integration, then the loop update
+                {
+                    do_correlation_step(in);
+                    save_correlation_results();
+                    if (!cn0_and_tracking_lock_status(d_code_period * static_cast<double>(trk_parameters.extend_correlation_symbols)))
+                        {
+                            clear_tracking_vars();
+                            d_state = 0;  // loss of lock
+                            break;
+                        }
+                    run_dll_pll();
+                    update_tracking_vars();
+                    fill_synchro(current_synchro_data);
+                    log_data(false);
+                    reset_accumulators();
+                    if (d_enable_extended_integration) d_state = 3;
                     break;
                 }
             default:
@@ -247,10 +375,80 @@ public:
     double rem_code_phase_samples() const { return d_rem_code_phase_samples; }
     uint64_t sample_counter() const { return d_sample_counter; }
     const std::vector<gr_complex>& correlator_outs() const { return d_correlator_outs; }
+    gr_complex prompt_data() const { return d_Prompt_Data; }
+    gr_complex prompt_accu() const { return d_P_accu; }
+    //! the reference waits 10 s before looking for the telemetry preamble (:1648); tests shorten it
+    void set_bit_sync_min_time_s(float t) { d_bit_sync_min_time_s = t; }
     const std::vector<int>& events() const { return d_events; }
     gc_status last_status() const { return multicorrelator_cpu.last_status(); }
 
 private:
+    void set_preamble(std::initializer_list<int> bits, int symbols_per_bit)
+    {
+        d_preambles_symbols.clear();
+        for (int bit : bits)
+            for (int j = 0; j < symbols_per_bit; j++) d_preambles_symbols.push_back(bit == 1 ? 1 : -1);
+        d_symbol_history.clear();
+    }
+
+    void reset_accumulators()
+    {
+        d_VE_accu = d_E_accu = d_P_accu = d_L_accu = d_VL_accu = gr_complex(0.0, 0.0);
+    }
+
+    //! what every valid period hands to the telemetry decoder (:1693-1725, :1789-1817, :1847-1878); E1-B and E1-C are in
+    //! anti-phase, not in quadrature, so I and Q are never interchanged for the signals mirrored here
+    void fill_synchro(Gnss_Synchro& d) const
+    {
+        const gr_complex p = trk_parameters.track_pilot ? d_Prompt_Data : d_correlator_outs[d_veml ? 2 : 1];
+        d.Prompt_I = static_cast<double>(p.real());
+        d.Prompt_Q = static_cast<double>(p.imag());
+        d.Code_phase_samples = d_rem_code_phase_samples;
+        d.Carrier_phase_rads = d_acc_carrier_phase_rad;
+        d.Carrier_Doppler_hz = d_carrier_doppler_hz;
+        d.CN0_dB_hz = d_CN0_SNV_dB_Hz;
+        d.correlation_length_ms = d_correlation_length_ms;
+        d.Flag_valid_symbol_output = true;
+    }
+
+    //! (:800-836) all of the last secondary_code_length prompt signs follow the secondary code, or all oppose it
+    bool acquire_secondary() const
+    {
+        int32_t corr_value = 0;
+        for (size_t i = 0; i < d_secondary_code_string.size(); i++)
+            {
+                const bool negative = d_Prompt_circular_buffer[i].real() < 0.0;
+                const bool zero = d_secondary_code_string[i] == '0';
+                corr_value += (negative == zero) ? 1 : -1;
+            }
+        return std::abs(corr_value) == static_cast<int32_t>(d_secondary_code_string.size());
+    }
+
+    //! (:1072-1125)
+    void save_correlation_results()
+    {
+        float sign = 1.0f;
+        if (d_secondary)
+            {
+                if (d_secondary_code_string[d_current_symbol] != '0') sign = -1.0f;
+                d_current_symbol = (d_current_symbol + 1) % static_cast<uint32_t>(d_secondary_code_string.size());
+            }
+        else
+            {
+                d_current_symbol++;
+                d_current_symbol %= static_cast<uint32_t>(d_symbols_per_bit);
+            }
+        if (d_veml)
+            {
+                d_VE_accu += sign * d_correlator_outs[0];
+                d_VL_accu += sign * d_correlator_outs[4];
+            }
+        d_E_accu += sign * d_correlator_outs[d_veml ? 1 : 0];
+        d_P_accu += sign * d_correlator_outs[d_veml ? 2 : 1];
+        d_L_accu += sign * d_correlator_outs[d_veml ? 3 : 2];
+        d_cloop = !trk_parameters.track_pilot;  // pilot: no symbol transitions left, four-quadrant PLL
+    }
+
     void set_tap_shifts()
     {
         // (:372-390, :720-732)
@@ -282,6 +480,17 @@ private:
             static_cast<float>(d_code_phase_step_chips) * static_cast<float>(d_code_samples_per_chip),
             static_cast<float>(d_code_phase_rate_step_chips) * static_cast<float>(d_code_samples_per_chip),
             trk_parameters.vector_length);
+        if (trk_parameters.track_pilot)
+            {
+                correlator_data_cpu.set_input_output_vectors(&d_Prompt_Data, input_samples);
+                correlator_data_cpu.Carrier_wipeoff_multicorrelator_resampler(
+                    d_rem_carr_phase_rad,
+                    d_carrier_phase_step_rad, d_carrier_phase_rate_step_rad,
+                    static_cast<float>(d_rem_code_phase_chips) * static_cast<float>(d_code_samples_per_chip),
+                    static_cast<float>(d_code_phase_step_chips) * static_cast<float>(d_code_samples_per_chip),
+                    static_cast<float>(d_code_phase_rate_step_chips) * static_cast<float>(d_code_samples_per_chip),
+                    trk_parameters.vector_length);
+            }
     }
 
     //! (:914-973)
@@ -317,7 +526,10 @@ private:
     void clear_tracking_vars()
     {
         std::fill(d_correlator_outs.begin(), d_correlator_outs.end(), gr_complex(0.0, 0.0));
+        if (trk_parameters.track_pilot) d_Prompt_Data = gr_complex(0.0, 0.0);
         d_P_accu_old = gr_complex(0.0, 0.0);
+        d_current_symbol = 0;
+        d_Prompt_circular_buffer.clear();
         d_carr_phase_error_hz = 0.0;
         d_carr_freq_error_hz = 0.0;
         d_carr_error_filt_hz = 0.0;
@@ -373,7 +585,7 @@ private:
 
     //! log_data (:1128-1250): one packed 96-byte record per epoch, the layout
     //! src/utils/matlab/libs/dll_pll_veml_read_tracking_dump.m and tracking_dump_reader.cc read
-    void log_data()
+    void log_data(bool integrating)
     {
         if (!d_dump_file.is_open()) return;
         auto put = [&](const void* p, size_t n) { d_dump_file.write(reinterpret_cast<const char*>(p), n); };
@@ -383,8 +595,15 @@ private:
         f[2] = std::abs(d_P_accu);
         f[3] = std::abs(d_L_accu);
         f[4] = d_veml ? std::abs(d_VL_accu) : 0.0f;
-        f[5] = d_P_accu.real();  // prompt I
-        f[6] = d_P_accu.imag();  // prompt Q
+        if (integrating && d_extend_correlation_symbols_count > 0)
+            {
+                // partial sums are scaled to the full integration length (:1176-1191)
+                const float scale_factor = static_cast<float>(trk_parameters.extend_correlation_symbols) / static_cast<float>(d_extend_correlation_symbols_count);
+                for (int i = 0; i < 5; i++) f[i] *= scale_factor;
+            }
+        const gr_complex p = trk_parameters.track_pilot ? d_Prompt_Data : d_correlator_outs[d_veml ? 2 : 1];
+        f[5] = p.real();  // prompt I
+        f[6] = p.imag();  // prompt Q
         put(f, sizeof f);
         uint64_t stamp = d_sample_counter + static_cast<uint64_t>(d_current_prn_length_samples);
         put(&stamp, sizeof stamp);
@@ -459,6 +678,18 @@ private:
     std::vector<float> d_local_code_shift_chips;
     std::vector<gr_complex> d_correlator_outs;
     Hip_Multicorrelator_Real_Codes multicorrelator_cpu;
+    Hip_Multicorrelator_Real_Codes correlator_data_cpu;  // pilot tracking: prompt of the data component
+    std::vector<float> d_data_code;
+    gr_complex d_Prompt_Data;
+    bool d_secondary = false;
+    bool d_enable_extended_integration = false;
+    std::string d_secondary_code_string;
+    std::vector<int32_t> d_preambles_symbols;
+    std::deque<gr_complex> d_Prompt_circular_buffer;  // capacity secondary_code_length
+    std::deque<float> d_symbol_history;               // capacity preamble_length_symbols
+    uint32_t d_current_symbol = 0;
+    int32_t d_extend_correlation_symbols_count = 0;
+    float d_bit_sync_min_time_s = 10.0f;
     gr_complex d_VE_accu, d_E_accu, d_P_accu, d_P_accu_old, d_L_accu, d_VL_accu;
     Tracking_loop_filter d_code_loop_filter;
     Tracking_FLL_PLL_filter d_carrier_loop_filter;

@@ -1,6 +1,8 @@
 // tracking_selftest.cpp -- closed-loop run of the tracking drop-in layer on the GPU (BASELINE configs[0]
 // shape: GPS L1 C/A, one channel, 4 Msps, PCPS acquisition followed by 3-tap DLL/PLL tracking), plus
-// Galileo E1 (5 taps, 4 ms) and BeiDou B1I hand-overs.  The input is a synthetic noiseless + noisy signal
+// Galileo E1 (5 taps, 4 ms) and BeiDou B1I hand-overs, and the synchronisation / extended-integration states: Galileo E1
+// pilot tracking (secondary-code lock, 4 x 4 ms integration, data symbols from the E1-B prompt), BeiDou NH20 lock, GPS
+// telemetry-preamble bit synchronisation with 20 ms integration.  The input is a synthetic noiseless + noisy signal
 // with known Doppler / code phase; the loop must pull in and stay locked, and its Doppler / C/N0 estimates
 // must converge to the truth.  Usage: tracking_selftest (needs a GPU).
 #include "dll_pll_tracking_adapters.h"
@@ -44,6 +46,35 @@ static std::vector<gr_complex> synth(const std::vector<float>& code, double chip
     return x;
 }
 
+// several components on one carrier, each with one symbol (+-1) per code period: period p of the stream carries
+// symbols[p % size]; period 0 is the partial one before the first code start
+struct Component
+{
+    std::vector<float> code;
+    std::vector<float> symbols;
+};
+static std::vector<gr_complex> synth_symbols(const std::vector<Component>& comps, double chip_rate_hz, double carrier_hz, double fs, size_t n, double fd,
+    double delay_samples, double cn0_dbhz, unsigned seed, double phi = 0.7)
+{
+    std::mt19937 gen(seed);
+    std::normal_distribution<float> nd(0.0f, std::sqrt(0.5f));
+    const double amp = std::sqrt(std::pow(10.0, cn0_dbhz / 10.0) / fs);
+    const double rate = chip_rate_hz * (1.0 + fd / carrier_hz) / fs;
+    const size_t L = comps[0].code.size();
+    const double tau0 = static_cast<double>(L) - delay_samples * chip_rate_hz / fs;
+    std::vector<gr_complex> x(n);
+    for (size_t i = 0; i < n; i++)
+        {
+            const double ph = 2.0 * M_PI * fd * static_cast<double>(i) / fs + phi;
+            const size_t k = static_cast<size_t>(std::floor(tau0 + static_cast<double>(i) * rate));
+            const size_t chip = k % L, period = k / L;
+            double v = 0.0;
+            for (const auto& c : comps) v += c.code[chip] * c.symbols[period % c.symbols.size()];
+            x[i] = gr_complex(static_cast<float>(amp * v * std::cos(ph)) + nd(gen), static_cast<float>(amp * v * std::sin(ph)) + nd(gen));
+        }
+    return x;
+}
+
 template <class Trk>
 static void run_tracking(Trk& trk, const std::vector<gr_complex>& x, Gnss_Synchro& syn, double true_doppler, double doppler_tol, double cn0_true, const char* name,
     int min_epochs)
@@ -67,7 +98,8 @@ static void run_tracking(Trk& trk, const std::vector<gr_complex>& x, Gnss_Synchr
             if (blk->state() == 0) break;
         }
     EXPECT(blk->last_status() == GC_OK, "%s: engine status %d (%s)", name, blk->last_status(), gc_last_error());
-    EXPECT(blk->state() == 2, "%s: lost lock (state %d after %d epochs)", name, blk->state(), epochs);
+    // a signal with one symbol per bit and no secondary code (Galileo E1-B alone) is handed to state 4 at once
+    EXPECT(blk->state() == 2 || blk->state() == 4, "%s: lost lock (state %d after %d epochs)", name, blk->state(), epochs);
     EXPECT(blk->events().empty(), "%s: loss-of-lock event", name);
     EXPECT(epochs >= min_epochs, "%s: only %d epochs", name, epochs);
     EXPECT(std::fabs(last_doppler - true_doppler) < doppler_tol, "%s: Doppler %.2f Hz, truth %.2f", name, last_doppler, true_doppler);
@@ -182,6 +214,193 @@ static void test_beidou_track()
     run_tracking(trk, x, syn, fd, 5.0, cn0, "BeiDou B1I tracking", 280);
 }
 
+static void test_galileo_pilot_extended()
+{
+    // E1-C pilot (secondary code CS25) drives the loop, 4 x 4 ms coherent integration after the secondary lock; the E1-B
+    // prompt (d_Prompt_Data) carries the data symbols to the telemetry decoder
+    const double fs = 4e6, fd = 2210.0, cn0 = 47.0, delay_samples = 3456.0;
+    Component b, c;
+    b.code.resize(8184);
+    c.code.resize(8184);
+    char sb[3] = "1B", sc[3] = "1C";
+    gc_galileo_e1_code_gen_sinboc11_float(b.code.data(), sb, 19);
+    gc_galileo_e1_code_gen_sinboc11_float(c.code.data(), sc, 19);
+    std::mt19937 gen(5);
+    for (int i = 0; i < 500; i++) b.symbols.push_back((gen() & 1u) ? 1.0f : -1.0f);
+    const std::string cs25 = "0011100000001010110110010";
+    for (char ch : cs25) c.symbols.push_back(ch == '0' ? 1.0f : -1.0f);
+    const int n_periods = 160;
+    auto x = synth_symbols({b, c}, 2.046e6, 1575.42e6, fs, 16000 * static_cast<size_t>(n_periods), fd, delay_samples, cn0, 21);
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+    config.set_property("Tracking_1B.track_pilot", "true");
+    config.set_property("Tracking_1B.extend_correlation_symbols", "4");
+    config.set_property("Tracking_1B.pll_bw_hz", "25.0");
+    config.set_property("Tracking_1B.dll_bw_hz", "2.0");
+    config.set_property("Tracking_1B.pll_bw_narrow_hz", "10.0");
+    config.set_property("Tracking_1B.dll_bw_narrow_hz", "0.5");
+    config.set_property("Tracking_1B.early_late_space_narrow_chips", "0.1");
+    config.set_property("Tracking_1B.very_early_late_space_narrow_chips", "0.5");
+    config.set_property("Tracking_1B.pull_in_time_s", "0");
+    Gnss_Synchro syn;
+    syn.System = 'E';
+    syn.Signal[0] = '1';
+    syn.Signal[1] = 'B';
+    syn.PRN = 19;
+    syn.Acq_delay_samples = delay_samples;
+    syn.Acq_doppler_hz = fd - 1.0;
+    syn.Acq_samplestamp_samples = 0;
+    GalileoE1DllPllVemlTrackingHip trk(&config, "Tracking_1B", 1, 1);
+    EXPECT(trk.conf().track_pilot && trk.conf().extend_correlation_symbols == 4, "pilot configuration not taken");
+    trk.set_gnss_synchro(&syn);
+    trk.start_tracking();
+    auto blk = trk.block();
+    size_t pos = 0;
+    int epochs = 0, first_ext = -1, agree = 0, counted = 0, updates = 0;
+    Gnss_Synchro out;
+    while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+        {
+            int produced = 0;
+            const int st_in = blk->state();
+            pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+            if (st_in < 2) continue;
+            if (blk->state() >= 3 && first_ext < 0) first_ext = epochs;
+            if (first_ext >= 0 && epochs > first_ext + 40 && produced)
+                {
+                    // tracked period k is stream period k + 2 (the pull-in skips the first complete one)
+                    counted++;
+                    if ((out.Prompt_I > 0) == (b.symbols[(epochs + 2) % b.symbols.size()] > 0)) agree++;
+                }
+            if (st_in == 4) updates++;
+            epochs++;
+        }
+    EXPECT(blk->last_status() == GC_OK, "pilot: engine status %d (%s)", blk->last_status(), gc_last_error());
+    EXPECT(blk->state() == 3 || blk->state() == 4, "pilot: state %d", blk->state());
+    // CS25 occupies stream periods 0..24, 25..49, ...: the first complete one seen by the loop ends at period 49 = epoch 47
+    EXPECT(first_ext == 47, "pilot: secondary code locked at epoch %d", first_ext);
+    EXPECT(updates >= (epochs - first_ext) / 4 - 1, "pilot: %d loop updates in %d periods", updates, epochs - first_ext);
+    EXPECT(counted > 50 && (agree == counted || agree == 0), "pilot: %d of %d data symbols agree", agree, counted);
+    EXPECT(std::fabs(blk->carrier_doppler_hz() - fd) < 2.0, "pilot: Doppler %.2f", blk->carrier_doppler_hz());
+    EXPECT(blk->events().empty(), "pilot: loss-of-lock event");
+    std::printf("Galileo E1 pilot tracking: secondary code locked at epoch %d, %d loop updates, %d / %d data symbols, Doppler %.2f Hz, C/N0 %.1f dB-Hz\n", first_ext, updates,
+        agree, counted, blk->carrier_doppler_hz(), blk->cn0_db_hz());
+}
+
+static void test_beidou_secondary_lock()
+{
+    const double fs = 4.092e6, fd = -900.0, cn0 = 47.0, delay_samples = 1500.0;
+    Component d;
+    d.code.resize(2046);
+    gc_beidou_b1i_code_gen_float(d.code.data(), 8, 0);
+    const std::string nh = "00000100110101001110";
+    for (char ch : nh) d.symbols.push_back(ch == '0' ? 1.0f : -1.0f);
+    auto x = synth_symbols({d}, 2.046e6, 1.561098e9, fs, 4092 * 300, fd, delay_samples, cn0, 22);
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "4092000");
+    config.set_property("Tracking_B1.pll_bw_hz", "40.0");
+    config.set_property("Tracking_B1.pull_in_time_s", "0");
+    Gnss_Synchro syn;
+    syn.System = 'C';
+    syn.Signal[0] = 'B';
+    syn.Signal[1] = '1';
+    syn.PRN = 8;
+    syn.Acq_delay_samples = delay_samples;
+    syn.Acq_doppler_hz = fd + 3.0;
+    syn.Acq_samplestamp_samples = 0;
+    BeidouB1iDllPllTrackingHip trk(&config, "Tracking_B1", 1, 1);
+    trk.set_gnss_synchro(&syn);
+    trk.start_tracking();
+    auto blk = trk.block();
+    size_t pos = 0;
+    int epochs = 0, first4 = -1;
+    Gnss_Synchro out;
+    while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+        {
+            int produced = 0;
+            const int st_in = blk->state();
+            pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+            if (st_in < 2) continue;
+            if (blk->state() == 4 && first4 < 0) first4 = epochs;
+            epochs++;
+        }
+    // NH20 occupies stream periods 0..19, 20..39: the first complete one seen by the loop ends at period 39 = epoch 37
+    EXPECT(first4 == 37 && blk->state() == 4, "BeiDou: NH20 locked at epoch %d, state %d", first4, blk->state());
+    EXPECT(std::fabs(blk->carrier_doppler_hz() - fd) < 5.0 && blk->events().empty(), "BeiDou: Doppler %.2f", blk->carrier_doppler_hz());
+    std::printf("BeiDou B1I: NH20 locked at epoch %d, state %d, Doppler %.2f Hz, C/N0 %.1f dB-Hz\n", first4, blk->state(), blk->carrier_doppler_hz(), blk->cn0_db_hz());
+}
+
+static void test_gps_bit_synchronisation()
+{
+    // telemetry preamble 10001011 inside random bits; the block waits bit_sync_min_time_s (10 s in the reference, shortened
+    // here), finds the preamble on the prompt signs and integrates 20 ms aligned with the bit edges.  Only the upright preamble
+    // counts, so the test tries both polarities of the stream: exactly one of them synchronises.
+    const double fs = 4e6, fd = 1500.0, cn0 = 50.0, delay_samples = 100.0;
+    Component d;
+    d.code.resize(1023);
+    gc_gps_l1_ca_code_gen_float(d.code.data(), 17, 0);
+    std::mt19937 gen(41);
+    std::vector<int> bits;
+    for (int i = 0; i < 6; i++) bits.push_back(gen() & 1u);
+    for (int b : {1, 0, 0, 0, 1, 0, 1, 1}) bits.push_back(b);
+    for (int i = 0; i < 8; i++) bits.push_back(gen() & 1u);
+    for (int b : bits)
+        for (int j = 0; j < 20; j++) d.symbols.push_back(b ? 1.0f : -1.0f);
+    int synced = 0;
+    for (float polarity : {1.0f, -1.0f})
+        {
+            Component c = d;
+            for (auto& v : c.symbols) v *= polarity;
+            auto x = synth_symbols({c}, 1.023e6, 1575.42e6, fs, 4000 * (20 * bits.size() - 10), fd, delay_samples, cn0, 23);
+            InMemoryConfiguration config;
+            config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+            config.set_property("Tracking_1C.extend_correlation_symbols", "20");
+            config.set_property("Tracking_1C.pll_bw_hz", "40.0");
+            config.set_property("Tracking_1C.pll_bw_narrow_hz", "10.0");
+            config.set_property("Tracking_1C.dll_bw_narrow_hz", "1.0");
+            config.set_property("Tracking_1C.pull_in_time_s", "0");
+            Gnss_Synchro syn;
+            syn.System = 'G';
+            syn.Signal[0] = '1';
+            syn.Signal[1] = 'C';
+            syn.PRN = 17;
+            syn.Acq_delay_samples = delay_samples;
+            syn.Acq_doppler_hz = fd + 4.0;
+            syn.Acq_samplestamp_samples = 0;
+            GpsL1CaDllPllTrackingHip trk(&config, "Tracking_1C", 1, 1);
+            trk.set_gnss_synchro(&syn);
+            auto blk = trk.block();
+            blk->set_bit_sync_min_time_s(0.03f);
+            trk.start_tracking();
+            size_t pos = 0;
+            int epochs = 0, first3 = -1;
+            double ratio = 0.0;
+            Gnss_Synchro out;
+            while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+                {
+                    int produced = 0;
+                    const int st_in = blk->state();
+                    pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+                    if (st_in < 2) continue;
+                    if (blk->state() == 3 && first3 < 0) first3 = epochs;
+                    if (st_in == 4 && first3 >= 0) ratio = std::abs(blk->correlator_outs()[1]);
+                    epochs++;
+                }
+            if (first3 >= 0)
+                {
+                    synced++;
+                    // the preamble's last symbol is stream period 20 * 14 - 1 = epoch 20 * 14 - 1 - 2
+                    EXPECT(first3 == 20 * 14 - 3, "GPS: bit synchronisation at epoch %d", first3);
+                    EXPECT(blk->state() == 3 || blk->state() == 4, "GPS: state %d", blk->state());
+                    EXPECT(std::fabs(blk->carrier_doppler_hz() - fd) < 3.0 && blk->events().empty(), "GPS: Doppler %.2f", blk->carrier_doppler_hz());
+                    std::printf("GPS L1 C/A: preamble found at epoch %d (polarity %+.0f), 20 ms integration, Doppler %.2f Hz, C/N0 %.1f dB-Hz, |P| %.0f\n", first3, polarity,
+                        blk->carrier_doppler_hz(), blk->cn0_db_hz(), ratio);
+                }
+            else
+                EXPECT(blk->state() == 2, "GPS: state %d without synchronisation", blk->state());
+        }
+    EXPECT(synced == 1, "GPS: %d of 2 polarities synchronised", synced);
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -221,6 +440,9 @@ int main()
     test_gps_acq_then_track();
     test_galileo_track();
     test_beidou_track();
+    test_galileo_pilot_extended();
+    test_beidou_secondary_lock();
+    test_gps_bit_synchronisation();
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

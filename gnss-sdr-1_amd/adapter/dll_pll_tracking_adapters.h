@@ -43,6 +43,7 @@ public:
         trk_param.high_dyn = configuration->property(role + ".high_dyn", false);
         trk_param.dump = configuration->property(role + ".dump", false);
         trk_param.dump_filename = configuration->property(role + ".dump_filename", std::string("./track_ch"));
+        trk_param.dump_mat = configuration->property(role + ".dump_mat", true);
         trk_param.smoother_length = std::max(1, configuration->property(role + ".smoother_length", 10));
         const bool gal = SIG == TrkSignal::GALILEO_E1;
         trk_param.pll_bw_hz = configuration->property(role + ".pll_bw_hz", gal ? 5.0f : 50.0f);

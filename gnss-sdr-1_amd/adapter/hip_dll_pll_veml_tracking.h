@@ -13,8 +13,9 @@
  * the loop, E1-B is demodulated), run_dll_pll (:914-973), update_tracking_vars (:998-1070) incl. the
  * high-dynamics rate smoother, cn0_and_tracking_lock_status (:839-878), the Gnss_Synchro record written
  * per epoch (:1693-1725, :1898-1906).
- * Not mirrored (outside the correlator hot path): the .mat conversion of the dump and the telemetry fault message
- * handler.  The binary dump itself (log_data, :1128-1250) is written in the reference's record layout.
+ * Not mirrored (outside the correlator hot path): the telemetry fault message handler.  The binary dump (log_data,
+ * :1128-1250) is written in the reference's record layout and converted to a .mat file with the reference's variable
+ * names when the block is destroyed (save_matfile, :1253-1438; Level-5 instead of v7.3, see mat5_writer.h).
  *
  * general_work(noutput, ninput_items, input_items, output_items) becomes
  * work(in, ninput_items, out): returns the number of input items consumed (consume_each) and sets
@@ -25,8 +26,10 @@
 
 #include "gnss_sdr_types.h"
 #include "hip_multicorrelator_real_codes.h"
+#include "mat5_writer.h"
 #include "tracking_loop_maths.h"
 #include <cmath>
+#include <cstring>
 #include <deque>
 #include <fstream>
 #include <mutex>
@@ -110,6 +113,65 @@ public:
         d_Prompt_buffer.assign(trk_parameters.cn0_samples, gr_complex(0.0, 0.0));
         d_carrier_lock_threshold = trk_parameters.carrier_lock_th;
         d_carr_ph_history_cap = 2 * trk_parameters.smoother_length;
+    }
+
+    //! (:750-797): closes the dump and, with dump_mat, converts it
+    ~hip_dll_pll_veml_tracking()
+    {
+        if (d_dump_file.is_open())
+            {
+                d_dump_file.close();
+                if (trk_parameters.dump_mat) save_matfile();
+            }
+    }
+
+    /*! save_matfile (:1253-1438): <dump_filename><channel>.dat -> .mat, one 1 x num_epoch array per field of the record */
+    int32_t save_matfile() const
+    {
+        std::string name = trk_parameters.dump_filename;
+        name.append(std::to_string(d_channel));
+        name.append(".dat");
+        std::ifstream in(name.c_str(), std::ios::binary | std::ios::ate);
+        if (!in.is_open()) return 1;
+        const size_t record = 96;  // 19 floats + uint64 + double + uint32, packed
+        const size_t num_epoch = static_cast<size_t>(in.tellg()) / record;
+        if (num_epoch == 0) return 1;
+        std::vector<char> raw(num_epoch * record);
+        in.seekg(0, std::ios::beg);
+        in.read(raw.data(), static_cast<std::streamsize>(raw.size()));
+        if (!in) return 1;
+        name.erase(name.length() - 4, 4);
+        name.append(".mat");
+        gnsscorr::Mat5Writer mat;
+        if (!mat.open(name)) return 1;
+        // field table of the record, in file order
+        struct Field
+        {
+            const char* name;
+            size_t offset, size;
+            uint32_t mx, mi;
+        };
+        using W = gnsscorr::Mat5Writer;
+        static const Field fields[] = {
+            {"abs_VE", 0, 4, W::mxSINGLE, W::miSINGLE}, {"abs_E", 4, 4, W::mxSINGLE, W::miSINGLE}, {"abs_P", 8, 4, W::mxSINGLE, W::miSINGLE},
+            {"abs_L", 12, 4, W::mxSINGLE, W::miSINGLE}, {"abs_VL", 16, 4, W::mxSINGLE, W::miSINGLE}, {"Prompt_I", 20, 4, W::mxSINGLE, W::miSINGLE},
+            {"Prompt_Q", 24, 4, W::mxSINGLE, W::miSINGLE}, {"PRN_start_sample_count", 28, 8, W::mxUINT64, W::miUINT64},
+            {"acc_carrier_phase_rad", 36, 4, W::mxSINGLE, W::miSINGLE}, {"carrier_doppler_hz", 40, 4, W::mxSINGLE, W::miSINGLE},
+            {"carrier_doppler_rate_hz", 44, 4, W::mxSINGLE, W::miSINGLE}, {"code_freq_chips", 48, 4, W::mxSINGLE, W::miSINGLE},
+            {"code_freq_rate_chips", 52, 4, W::mxSINGLE, W::miSINGLE}, {"carr_error_hz", 56, 4, W::mxSINGLE, W::miSINGLE},
+            {"carr_error_filt_hz", 60, 4, W::mxSINGLE, W::miSINGLE}, {"code_error_chips", 64, 4, W::mxSINGLE, W::miSINGLE},
+            {"code_error_filt_chips", 68, 4, W::mxSINGLE, W::miSINGLE}, {"CN0_SNV_dB_Hz", 72, 4, W::mxSINGLE, W::miSINGLE},
+            {"carrier_lock_test", 76, 4, W::mxSINGLE, W::miSINGLE}, {"aux1", 80, 4, W::mxSINGLE, W::miSINGLE}, {"aux2", 84, 8, W::mxDOUBLE, W::miDOUBLE},
+            {"PRN", 92, 4, W::mxUINT32, W::miUINT32}};
+        std::vector<char> column(num_epoch * 8);
+        bool ok = true;
+        for (const Field& f : fields)
+            {
+                for (size_t e = 0; e < num_epoch; e++) std::memcpy(&column[e * f.size], &raw[e * record + f.offset], f.size);
+                ok = ok && mat.write_array(f.name, f.mx, f.mi, f.size, 1, num_epoch, column.data());
+            }
+        mat.close();
+        return ok ? 0 : 1;
     }
 
     //! set_channel (:1442-1480): with Tracking_XX.dump the binary dump file "<dump_filename><channel>.dat" is opened here

@@ -1,7 +1,7 @@
 /*!
  * \file mat5_writer.h
  * \brief Minimal writer of MATLAB Level-5 MAT-files (uncompressed), enough for the variables the
- * reference's acquisition dump holds (pcps_acquisition.cc:462-562).
+ * reference's acquisition dump (pcps_acquisition.cc:462-562) and tracking dump (dll_pll_veml_tracking.cc:1253-1438) hold.
  *
  * The reference writes its dump through matio as a v7.3 (HDF5) file; neither matio nor HDF5 is a
  * dependency here, so the same variables (names, classes, dimensions, column-major data) go into a
@@ -24,6 +24,7 @@ public:
     // array classes (mx*_CLASS) and data types (mi*) of the MAT-file format
     enum : uint32_t
     {
+        mxDOUBLE = 6,
         mxSINGLE = 7,
         mxINT32 = 12,
         mxUINT32 = 13,
@@ -35,6 +36,7 @@ public:
         miINT32 = 5,
         miUINT32 = 6,
         miSINGLE = 7,
+        miDOUBLE = 9,
         miUINT64 = 13,
         miMATRIX = 14
     };
@@ -51,7 +53,7 @@ public:
         if (d_fp == nullptr) return false;
         char hdr[128];
         std::memset(hdr, ' ', 116);
-        const char* text = "MATLAB 5.0 MAT-file, Platform: gnsscorr, acquisition dump";
+        const char* text = "MATLAB 5.0 MAT-file, Platform: gnsscorr, dump";
         std::memcpy(hdr, text, std::strlen(text));
         std::memset(hdr + 116, 0, 8);  // subsystem data offset: none
         const uint16_t version = 0x0100;

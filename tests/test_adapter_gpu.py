@@ -111,6 +111,16 @@ def test_cpp_closed_loop_tracking_selftest():
         assert abs(dump["carrier_doppler_hz"][-50:].mean() - 1680.0) < 3.0
         assert np.allclose(np.hypot(dump["prompt_I"], dump["prompt_Q"]), dump["abs_P"], rtol=1e-6)
         assert dump["abs_P"][-100:].mean() > dump["abs_E"][-100:].mean() > 0.3 * dump["abs_P"][-100:].mean()
+        # ... and is converted to a .mat file with the variable names of save_matfile (:1253-1438) when the block is destroyed
+        import scipy.io
+        classes = {name: (shape, cls) for name, shape, cls in scipy.io.whosmat(os.path.join(d, "track_ch0.mat"))}
+        assert len(classes) == 22 and classes["abs_P"] == ((1, dump.size), "single") and classes["aux2"] == ((1, dump.size), "double")
+        assert classes["PRN_start_sample_count"] == ((1, dump.size), "uint64") and classes["PRN"] == ((1, dump.size), "uint32")
+        m = scipy.io.loadmat(os.path.join(d, "track_ch0.mat"))
+        for mat_name, field in (("abs_E", "abs_E"), ("Prompt_I", "prompt_I"), ("Prompt_Q", "prompt_Q"), ("carrier_doppler_hz", "carrier_doppler_hz"),
+                ("carr_error_hz", "carr_error_hz"), ("CN0_SNV_dB_Hz", "CN0_SNV_dB_Hz"), ("PRN_start_sample_count", "PRN_start_sample_count"),
+                ("aux2", "aux2"), ("PRN", "PRN"), ("code_freq_rate_chips", "code_freq_rate_chips")):
+            assert np.array_equal(m[mat_name][0], dump[field]), mat_name
 
 
 @pytest.mark.parametrize("prog", ["adapter_selftest", "tracking_selftest"])

@@ -292,3 +292,83 @@ def test_randomised_level1_call_sequences(gctx, oracle):
             assert float(np.max(np.abs(out - ref))) <= tol, (obj, call, n, off, out, ref)
         mc.free()
         mc.close()
+
+
+def _random_loop_case(rng):
+    """A random signal + loop configuration for the closed-loop state machine (synchronisation, extension, pilot)."""
+    from test_loop_sync_gpu import _stream
+    veml = bool(rng.integers(0, 2))
+    spc = 2 if veml else 1
+    L = int(rng.integers(150, 1200)) * spc            # code samples per period
+    fs = float(rng.integers(2000, 5000)) * 1000.0     # 1 ms code period
+    N = int(round(fs * 0.001))
+    code = (rng.integers(0, 2, L) * 2 - 1).astype(np.float32)
+    data_code = (rng.integers(0, 2, L) * 2 - 1).astype(np.float32)
+    kind = rng.choice(["secondary", "preamble", "single"])
+    pilot = kind == "secondary" and rng.uniform() < 0.7
+    ext = int(rng.integers(1, 6))
+    y = dict(extend_correlation_symbols=ext, track_pilot=pilot, pll_bw_narrow_hz=float(rng.uniform(8, 20)), dll_bw_narrow_hz=float(rng.uniform(0.5, 2.0)),
+        early_late_space_narrow_chips=float(rng.uniform(0.1, 0.4)), very_early_late_space_narrow_chips=float(rng.uniform(0.45, 0.6)))
+    n_ep = 70 + 6 * ext
+    shift = int(rng.integers(0, 12))
+    if kind == "secondary":
+        sec = "".join(rng.choice(["0", "1"], int(rng.integers(4, 31))))
+        if len(set(sec)) == 1:
+            sec = sec[:-1] + ("1" if sec[0] == "0" else "0")
+        y.update(symbols_per_bit=int(rng.integers(1, 21)), secondary_code=sec)
+        sym = np.roll(np.array([1.0 if c == "0" else -1.0 for c in sec]), shift)
+    elif kind == "preamble":
+        spb = int(rng.integers(2, 6))
+        bits = [int(b) for b in rng.integers(0, 2, int(rng.integers(3, 7)))]
+        pre = [1 if b else -1 for b in bits for _ in range(spb)]
+        y.update(symbols_per_bit=spb, preamble_symbols=pre, bit_sync_min_time_s=float(rng.uniform(0.0, 0.02)))
+        # random bits, the preamble, random bits -- in both polarities over the cases
+        allbits = [int(b) for b in rng.integers(0, 2, 4)] + bits + [int(b) for b in rng.integers(0, 2, 40)]
+        sym = np.roll(np.repeat(np.array(allbits) * 2.0 - 1.0, spb), shift) * (1.0 if rng.integers(0, 2) else -1.0)
+    else:
+        y.update(symbols_per_bit=1)
+        sym = np.array([1.0])
+    doppler = float(rng.uniform(-4000, 4000))
+    delay = float(rng.integers(0, N))
+    comps = [(code, sym, 1.0)]
+    if pilot:
+        comps.append((data_code, rng.integers(0, 2, 97) * 2.0 - 1.0, 1.0))
+    x = _stream(comps, fs, N * (n_ep + 3), doppler, delay, float(rng.uniform(47, 52)), int(rng.integers(1, 1 << 30)), L * 1000.0)
+    conf = dict(fs_in=fs, signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=L * 1000.0 / spc, code_period_s=0.001, carrier_lock_th=0.85,
+        code_length_chips=L // spc, code_samples_per_chip=spc, vector_length=N, pull_in_time_s=0, veml=int(veml), pll_filter_order=int(rng.integers(2, 4)),
+        dll_filter_order=int(rng.integers(1, 4)), enable_fll_pull_in=0, enable_fll_steady_state=int(rng.integers(0, 2)), cn0_samples=int(rng.integers(5, 21)),
+        cn0_min=25, max_lock_fail=50, pll_bw_hz=float(rng.uniform(25, 45)), dll_bw_hz=float(rng.uniform(1, 3)), fll_bw_hz=10.0,
+        early_late_space_chips=float(rng.uniform(0.2, 0.5)), very_early_late_space_chips=float(rng.uniform(0.55, 0.7)), acq_samplestamp_samples=0,
+        sample_counter=0, acq_delay_samples=delay, acq_doppler_hz=doppler + float(rng.uniform(-3, 3)))
+    return x, code, (data_code if pilot else None), conf, y, n_ep, (5 if veml else 3)
+
+
+def test_randomised_loop_state_machine(gctx, oracle):
+    """Closed-loop engine vs the Python restatement over random synchronisation set-ups: random replicas and code lengths,
+    3 / 5 taps, secondary codes of 4..30 symbols with and without a pilot + data component, preambles in both polarities,
+    1..5 symbol integrations, loop-filter orders, FLL assistance.  State sequence and block boundaries must be identical."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    from test_loop_sync_gpu import _compare, _conf, _sync
+    seed = int(os.environ.get("GNSSCORR_FUZZ_SEED", "20240611"))
+    rng = np.random.Generator(np.random.PCG64(seed + 5))
+    reached = {2: 0, 3: 0, 4: 0}
+    for case in range(int(os.environ.get("GNSSCORR_FUZZ_LOOP_CASES", "24"))):
+        x, code, data_code, conf, y, n_ep, n_taps = _random_loop_case(rng)
+        ref = ref_run(oracle, x, code, conf, n_ep, sync=y, data_code=data_code)
+        d = torch.from_numpy(x.view(np.float32)).cuda()
+        loop = gnsscorr.TrackingLoop(gctx, 1, code.size)
+        loop.set_input_dev(0, d.data_ptr(), x.size)
+        loop.set_sync(0, _sync(gnsscorr, y), data_code)
+        loop.start(0, _conf(gnsscorr, **conf), code)
+        # the same epochs in two launches: the state machine's state lives on the device between them
+        k = int(rng.integers(1, n_ep))
+        rec = np.concatenate([loop.run(k)[0], loop.run(n_ep - k)[0]])
+        loop.close()
+        try:
+            _compare(rec[:len(ref)], ref, n_taps, tol=5e-3, abs_tol=2.2 * float(np.abs(x).max()))
+        except AssertionError as e:
+            raise AssertionError("case %d (seed %d): %s\nsync %r" % (case, seed, e, y)) from e
+        reached[int(rec["state"][len(ref) - 1])] = reached.get(int(rec["state"][len(ref) - 1]), 0) + 1
+    assert reached[3] + reached[4] >= 4, reached  # a fair share of the cases did synchronise

@@ -48,7 +48,10 @@ def _stream(components, fs, n, doppler, delay, cn0, seed, chip_rate_samples, car
     return x.astype(np.complex64)
 
 
-def _compare(rec, ref, n_taps, tol=3e-3):
+def _compare(rec, ref, n_taps, tol=3e-3, abs_tol=0.0):
+    """abs_tol: what one sample on the other side of a chip edge may change in a tap sum (2 |x|).  The device computes the
+    NCO scalars with its own double-precision libm; a last-bit difference in one of them, rounded to float, moves a chip edge
+    by less than 1e-7 chip -- with short integrations that is visible as a single sample now and then."""
     assert len(ref) == len(rec)
     pi = n_taps // 2
     for k in range(len(ref)):
@@ -58,14 +61,15 @@ def _compare(rec, ref, n_taps, tol=3e-3):
         assert int(g["valid"]) == r["valid"] and int(g["integrating"]) == r["integrating"] and int(g["extend_count"]) == r["ext_count"], k
         scale = abs(r["corr"][pi]) + 1e-9
         gc = g["corr"][0:2 * n_taps:2] + 1j * g["corr"][1:2 * n_taps:2]
-        assert np.max(np.abs(gc - r["corr"])) <= tol * scale, k
+        assert np.max(np.abs(gc - r["corr"])) <= max(tol * scale, abs_tol), k
         gd = g["prompt_data"][0] + 1j * g["prompt_data"][1]
-        assert abs(gd - r["prompt_data"]) <= tol * max(scale, abs(r["prompt_data"])), k
+        assert abs(gd - r["prompt_data"]) <= max(tol * max(scale, abs(r["prompt_data"])), abs_tol), k
         ga = g["accu"][0::2] + 1j * g["accu"][1::2]
-        assert np.max(np.abs(ga - r["accu"])) <= tol * max(scale, np.max(np.abs(r["accu"]))), k
-        assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.05, k
-        assert abs(float(g["code_error_chips"]) - r["cerr"]) < 3e-3, k
-        assert abs(float(g["cn0_db_hz"]) - r["cn0"]) < 0.05 and abs(float(g["carrier_lock_test"]) - r["lock_test"]) < 2e-3, k
+        assert np.max(np.abs(ga - r["accu"])) <= max(tol * max(scale, np.max(np.abs(r["accu"]))), 4 * abs_tol), k
+        loose = abs_tol / scale  # relative size of one sample in a tap (0 for the fixed scenarios)
+        assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.05 + 40 * loose, k
+        assert abs(float(g["code_error_chips"]) - r["cerr"]) < 3e-3 + 2 * loose, k
+        assert abs(float(g["cn0_db_hz"]) - r["cn0"]) < 0.05 + 40 * loose and abs(float(g["carrier_lock_test"]) - r["lock_test"]) < 2e-3 + 2 * loose, k
 
 
 GAL = dict(fs_in=4e6, signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=1.023e6, code_period_s=0.004, carrier_lock_th=0.85,

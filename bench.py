@@ -448,6 +448,41 @@ def main():
                 "note": "256 channels tracked in closed loop (DLL/PLL maths on the device), one workgroup per channel, shared RF stream"}
             loop.close()
 
+            # Galileo E1 closed loop, 5 taps, 4 ms periods, data component alone vs pilot tracking (E1-C drives the loop,
+            # the E1-B prompt is one extra LDS lookup on the prompt tap's chip index)
+            n_g, e_g, n_len = 128, max(2, min(E, 64) // 4), 4 * N_EPOCH
+            rng_g = np.random.Generator(np.random.PCG64(77))
+            e1c = np.sign(rng_g.standard_normal(8184)).astype(np.float32)
+            e1b = np.sign(rng_g.standard_normal(8184)).astype(np.float32)
+            gres = {}
+            for pilot in (False, True):
+                gl = gnsscorr.TrackingLoop(ctx, n_g, 8184)
+                glc = gnsscorr.LoopConf()
+                for k_, v_ in dict(fs_in=float(FS), signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=1.023e6, code_period_s=0.004, carrier_lock_th=0.85,
+                        code_length_chips=4092, code_samples_per_chip=2, vector_length=n_len, pull_in_time_s=2, veml=1, pll_filter_order=3,
+                        dll_filter_order=2, cn0_samples=20, cn0_min=25, max_lock_fail=50, pll_bw_hz=15.0, dll_bw_hz=0.75, fll_bw_hz=10.0,
+                        early_late_space_chips=0.15, very_early_late_space_chips=0.6, acq_delay_samples=0.0, acq_doppler_hz=1000.0).items():
+                    setattr(glc, k_, v_)
+                d_grecs = torch.zeros(n_g * e_g * gnsscorr.LOOP_RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+                def gl_run():
+                    for ch in range(n_g):
+                        gl.set_input_dev(ch, streams[0].data_ptr(), n_stream)
+                        gl.set_sync(ch, gnsscorr.LoopSyncConf.make(extend_correlation_symbols=1, track_pilot=pilot, symbols_per_bit=1), e1b if pilot else None)
+                        gl.start(ch, glc, e1c)
+                    torch.cuda.synchronize()
+                    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    c0.record()
+                    gl.run_dev(e_g, d_grecs.data_ptr(), stream)
+                    c1.record()
+                    torch.cuda.synchronize()
+                    return c0.elapsed_time(c1)
+                gl_run()
+                gres[pilot] = min(gl_run() for _ in range(3))
+                gl.close()
+            extra["closed_loop_galileo_e1"] = {"channels": n_g, "periods": e_g, "ms_data_only": gres[False], "ms_pilot": gres[True],
+                "realtime_factor_pilot": e_g * 4.0 / gres[True], "value": n_g * e_g * n_len / (gres[True] * 1e-3) / 1e6, "unit": "Msamples/s",
+                "note": "128 channels x 5 taps x 100000-sample periods in closed loop on a shared stream; pilot = 5 taps + the data component's prompt"}
+
         # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----
         if not args.no_acq:
             acq = gnsscorr.PcpsAcquisition(ctx, 32, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,

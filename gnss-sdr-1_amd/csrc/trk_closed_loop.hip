@@ -85,7 +85,7 @@ struct LoopChan
 };
 
 // ---- loop filter design: tracking_loop_filter.cc:104-245 (include_last_integrator == false) ----
-static __device__ void dll_design(DevLoopFilter& f, int order, float bw, float T)
+static __device__ __forceinline__ void dll_design(DevLoopFilter& f, int order, float bw, float T)
 {
     const float zeta = 1.0 / sqrt(2.0);
     float g1, g2, g3, wn;
@@ -127,13 +127,13 @@ static __device__ void dll_design(DevLoopFilter& f, int order, float bw, float T
         }
 }
 
-static __device__ void dll_initialize(DevLoopFilter& f)
+static __device__ __forceinline__ void dll_initialize(DevLoopFilter& f)
 {
     for (int i = 0; i < 4; i++) f.in[i] = f.out[i] = 0.0f;
     f.idx = 3;
 }
 
-static __device__ float dll_apply(DevLoopFilter& f, float v)
+static __device__ __forceinline__ float dll_apply(DevLoopFilter& f, float v)
 {
     float result = 0.0f;
     for (int i = 0; i < f.na; ++i) result += f.a[i] * f.out[(f.idx + i) % 4];
@@ -146,7 +146,7 @@ static __device__ float dll_apply(DevLoopFilter& f, float v)
 }
 
 // ---- carrier loop filter: tracking_FLL_PLL_filter.cc:55-133 ----
-static __device__ void pll_set_params(DevPll& p, float fll_bw_hz, float pll_bw_hz, int order)
+static __device__ __forceinline__ void pll_set_params(DevPll& p, float fll_bw_hz, float pll_bw_hz, int order)
 {
     p.order = order;
     p.w = p.x = p.a3 = p.b3 = p.w0p3 = p.w0f2 = 0.0f;
@@ -171,7 +171,7 @@ static __device__ void pll_set_params(DevPll& p, float fll_bw_hz, float pll_bw_h
 }
 
 // set_params on a running filter (:1754): new coefficients, integrators untouched
-static __device__ void pll_retune(DevPll& p, float fll_bw_hz, float pll_bw_hz, int order)
+static __device__ __forceinline__ void pll_retune(DevPll& p, float fll_bw_hz, float pll_bw_hz, int order)
 {
     const float w = p.w, x = p.x;
     pll_set_params(p, fll_bw_hz, pll_bw_hz, order);
@@ -179,7 +179,7 @@ static __device__ void pll_retune(DevPll& p, float fll_bw_hz, float pll_bw_hz, i
     p.x = x;
 }
 
-static __device__ float pll_get_carrier_error(DevPll& p, float fll, float pll, float T)
+static __device__ __forceinline__ float pll_get_carrier_error(DevPll& p, float fll, float pll, float T)
 {
     float carrier_error_hz;
     if (p.order == 3)
@@ -249,7 +249,7 @@ static __device__ void loop_start(LoopChan& s)
 }
 
 // cn0_and_tracking_lock_status (:839-878); false = loss of lock
-static __device__ bool loop_lock_status(LoopChan& s, double coh_integration_time_s)
+static __device__ __forceinline__ bool loop_lock_status(LoopChan& s, double coh_integration_time_s)
 {
     const gc_loop_conf& c = s.conf;
     if (s.cn0_estimation_counter < c.cn0_samples)
@@ -293,7 +293,7 @@ static __device__ bool loop_lock_status(LoopChan& s, double coh_integration_time
 }
 
 // clear_tracking_vars (:976-995)
-static __device__ void loop_clear_tracking_vars(LoopChan& s)
+static __device__ __forceinline__ void loop_clear_tracking_vars(LoopChan& s)
 {
     s.prompt_data = make_float2(0.f, 0.f);
     s.P_accu_old = make_float2(0.f, 0.f);
@@ -305,7 +305,7 @@ static __device__ void loop_clear_tracking_vars(LoopChan& s)
 }
 
 // run_dll_pll (:914-973) on the accumulators
-static __device__ void loop_run_dll_pll(LoopChan& s, bool veml)
+static __device__ __forceinline__ void loop_run_dll_pll(LoopChan& s, bool veml)
 {
     const gc_loop_conf& c = s.conf;
     const float2 VE = s.accu[0], E = s.accu[1], P = s.accu[2], L = s.accu[3], VL = s.accu[4];
@@ -343,7 +343,7 @@ static __device__ void loop_run_dll_pll(LoopChan& s, bool veml)
 }
 
 // update_tracking_vars (:998-1070), no high-dynamics terms
-static __device__ void loop_update_tracking_vars(LoopChan& s)
+static __device__ __forceinline__ void loop_update_tracking_vars(LoopChan& s)
 {
     const gc_loop_conf& c = s.conf;
     const double T_prn_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
@@ -360,7 +360,7 @@ static __device__ void loop_update_tracking_vars(LoopChan& s)
 }
 
 // save_correlation_results (:1072-1125): accumulate with the secondary-code sign
-static __device__ void loop_save_correlation_results(LoopChan& s, const float2* taps, bool veml)
+static __device__ __forceinline__ void loop_save_correlation_results(LoopChan& s, const float2* taps, bool veml)
 {
     const LoopSync& y = s.sync;
     float sign = 1.0f;
@@ -396,7 +396,7 @@ static __device__ void loop_save_correlation_results(LoopChan& s, const float2* 
 
 // pushes the sign of the prompt into the history; true when the last `len` signs match `pattern`
 // (exactly == all bits equal; or, for the secondary code, all bits opposite as well)
-static __device__ bool loop_push_and_match(LoopChan& s, float prompt_re, int len, const unsigned* pattern, bool either_polarity)
+static __device__ __forceinline__ bool loop_push_and_match(LoopChan& s, float prompt_re, int len, const unsigned* pattern, bool either_polarity)
 {
     const unsigned neg = prompt_re < 0.0f ? 1u : 0u;
     for (int w = 5; w > 0; w--) s.hist[w] = (s.hist[w] << 1) | (s.hist[w - 1] >> 31);
@@ -413,7 +413,7 @@ static __device__ bool loop_push_and_match(LoopChan& s, float prompt_re, int len
     return either_polarity ? (diff == 0 || diff == len) : diff == len;
 }
 
-static __device__ void loop_write_record(const LoopChan& s, gc_loop_record* rec, int valid, int integrating, int extend_count)
+static __device__ __forceinline__ void loop_write_record(const LoopChan& s, gc_loop_record* rec, int valid, int integrating, int extend_count)
 {
     for (int t = 0; t < 5; t++)
         {
@@ -427,7 +427,7 @@ static __device__ void loop_write_record(const LoopChan& s, gc_loop_record* rec,
 
 // everything general_work does with one code period's correlator outputs (states 2, 3, 4; :1601-1896)
 template <int NTAPS, bool DATA>
-static __device__ void loop_after_correlation(LoopChan& s, const float2* taps, gc_loop_record* rec)
+static __device__ __forceinline__ void loop_after_correlation(LoopChan& s, const float2* taps, gc_loop_record* rec)
 {
     const gc_loop_conf& c = s.conf;
     const LoopSync& y = s.sync;

@@ -6,6 +6,10 @@
 //   beidou_b1i_code_gen_float / _complex_sampled   (src/algorithms/libs/beidou_b1i_signal_processing.cc:115-191)
 //   glonass_l1_ca_code_gen_complex / _complex_sampled (src/algorithms/libs/glonass_l1_signal_processing.cc:37-153; L2 C/A is the same code)
 //   galileo_e1_code_gen_sinboc11_float / _complex_sampled (src/algorithms/libs/galileo_e1_signal_processing.cc:108-255)
+//   gps_l2c_m_code_gen_float / _complex_sampled    (src/algorithms/libs/gps_l2c_signal.cc:44-137)
+//   gps_l5i / gps_l5q _code_gen_float / _complex_sampled (src/algorithms/libs/gps_l5_signal.cc:41-344)
+//   beidou_b3i_code_gen_float / _complex_sampled   (src/algorithms/libs/beidou_b3i_signal_processing.cc:37-246)
+//   galileo_e5_a_code_gen_complex_primary / _sampled (src/algorithms/libs/galileo_e5_signal_processing.cc:38-142)
 //   resampler()                                    (src/algorithms/libs/gnss_signal_processing.cc:161-182)
 // written from the signal ICDs (IS-GPS-200 G1/G2 registers and G2 delays, BDS-SIS-ICD-B1I
 // G1/G2 registers and phase selectors, Galileo OS SIS ICD memory codes) as word-wide LFSRs.
@@ -195,6 +199,192 @@ bool galileo_primary(int8_t* out, const char* signal, unsigned prn)
     for (int i = 0; i < 4092; i++) out[i] = ((p[i >> 3] >> (7 - (i & 7))) & 1) ? -1 : 1;
     return true;
 }
+
+// ---- per-PRN constants of the 10.23 / 0.5115 Mcps signals: data/prn_tables.bin, data/galileo_e5a_primary_codes.bin ----
+struct PrnTables
+{
+    std::vector<int32_t> l2c_init, l5i_advance, l5q_advance, b3i_phase;
+    int n_e5a_q_secondary = 0;
+    std::string e5a_q_secondary;  // 50 x 100 characters
+    std::string e5a_i_secondary;  // 20 characters
+    std::vector<uint8_t> e5a_bits;  // [2 (I,Q)][50][1279] bytes, MSB first, bit 1 -> chip -1
+    bool loaded = false;
+};
+std::mutex g_tab_mtx;
+PrnTables g_tab;
+
+std::string data_file(const char* name)
+{
+    const char* env = std::getenv("GNSSCORR_DATA_DIR");
+    if (env && *env) return std::string(env) + "/" + name;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&default_galileo_path), &info) && info.dli_fname)
+        {
+            std::string p(info.dli_fname);
+            size_t s = p.find_last_of('/');
+            return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/data/" + name;
+        }
+    return std::string("data/") + name;
+}
+
+bool read_all(const std::string& path, std::vector<uint8_t>& buf)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    buf.resize(n > 0 ? static_cast<size_t>(n) : 0);
+    size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), f);
+    std::fclose(f);
+    return got == buf.size();
+}
+
+bool load_tables()
+{
+    std::lock_guard<std::mutex> lk(g_tab_mtx);
+    if (g_tab.loaded) return true;
+    std::vector<uint8_t> raw;
+    const std::string path = data_file("prn_tables.bin");
+    if (!read_all(path, raw) || raw.size() < 28 || std::memcmp(raw.data(), "GCPRNTB1", 8) != 0)
+        {
+            gc_set_error("PRN tables not found (or not a table file) at %s", path.c_str());
+            return false;
+        }
+    int32_t n[5];
+    std::memcpy(n, raw.data() + 8, sizeof n);
+    const size_t need = 28 + 4 * (static_cast<size_t>(n[0]) + n[1] + n[2] + n[3]) + 50 * 100 + 20;
+    if (n[0] != 115 || n[1] != 210 || n[2] != 210 || n[3] != 63 || n[4] < 0 || n[4] > 50 || raw.size() != need)
+        {
+            gc_set_error("PRN table file %s has an unexpected layout", path.c_str());
+            return false;
+        }
+    const uint8_t* p = raw.data() + 28;
+    auto take = [&](std::vector<int32_t>& v, int count) {
+        v.resize(count);
+        std::memcpy(v.data(), p, 4 * static_cast<size_t>(count));
+        p += 4 * static_cast<size_t>(count);
+    };
+    PrnTables t;
+    take(t.l2c_init, n[0]);
+    take(t.l5i_advance, n[1]);
+    take(t.l5q_advance, n[2]);
+    take(t.b3i_phase, n[3]);
+    t.n_e5a_q_secondary = n[4];
+    t.e5a_q_secondary.assign(reinterpret_cast<const char*>(p), 50 * 100);
+    t.e5a_i_secondary.assign(reinterpret_cast<const char*>(p) + 50 * 100, 20);
+    const std::string path5 = data_file("galileo_e5a_primary_codes.bin");
+    if (!read_all(path5, t.e5a_bits) || t.e5a_bits.size() != 2u * 50u * 1279u)
+        {
+            gc_set_error("Galileo E5a memory codes not found (or truncated) at %s", path5.c_str());
+            return false;
+        }
+    t.loaded = true;
+    g_tab = std::move(t);
+    return true;
+}
+
+// ---- GPS L2 CM (IS-GPS-200, 3.2.1.4 / Fig. 3-12): 27-stage modular shift register, polynomial 1112225171 (octal),
+// short-cycled to 10230 chips; the per-PRN initial states are Table 3-IIa ----
+bool gps_l2cm_chips(int8_t* out, unsigned prn)
+{
+    if (prn < 1 || prn > 50 || !load_tables()) return false;
+    uint32_t x = static_cast<uint32_t>(g_tab.l2c_init[prn - 1]);
+    for (int n = 0; n < 10230; n++)
+        {
+            out[n] = (x & 1u) ? -1 : 1;  // 1 - 2 * bit
+            x = (x >> 1) ^ ((x & 1u) ? 0445112474u : 0u);
+        }
+    return true;
+}
+
+// ---- GPS L5 (IS-GPS-705, 3.2.1.1): XA = 1+x^9+x^10+x^12+x^13 short-cycled at 8190, XB = 1+x+x^3+x^4+x^6+x^7+x^8+x^12+x^13,
+// both from all ones; chip n = XA(n) xor XB(n + advance).  Like the reference, the advanced XB index wraps at the 10230-chip
+// length of the generated XB run (gps_l5_signal.cc:137-147), not at XB's natural period ----
+bool gps_l5_chips(int8_t* out, unsigned prn, bool q_component)
+{
+    if (prn < 1 || prn > 50 || !load_tables()) return false;
+    static uint8_t xa[10230], xb[10230];
+    static bool built = false;
+    static std::mutex mtx;
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        if (!built)
+            {
+                unsigned ra = 0x1fff, rb = 0x1fff;  // bit k = stage k+1; the output is stage 13
+                for (int i = 0; i < 10230; i++)
+                    {
+                        xa[i] = (ra >> 12) & 1;
+                        xb[i] = (rb >> 12) & 1;
+                        if (ra == (0x1fffu & ~(1u << 11)))
+                            ra = 0x1fff;  // decoded state 1111111111101: the 8190-chip short cycle
+                        else
+                            ra = ((ra << 1) | (((ra >> 12) ^ (ra >> 11) ^ (ra >> 9) ^ (ra >> 8)) & 1u)) & 0x1fff;
+                        rb = ((rb << 1) | (((rb >> 12) ^ (rb >> 11) ^ (rb >> 7) ^ (rb >> 6) ^ (rb >> 5) ^ (rb >> 3) ^ (rb >> 2) ^ rb) & 1u)) & 0x1fff;
+                    }
+                built = true;
+            }
+    }
+    const int adv = (q_component ? g_tab.l5q_advance : g_tab.l5i_advance)[prn - 1];
+    for (int n = 0; n < 10230; n++) out[n] = (xa[n] ^ xb[(adv + n) % 10230]) ? -1 : 1;
+    return true;
+}
+
+// ---- BeiDou B3I (BDS-SIS-ICD-B3I, 4.2): G1 = 1+x+x^3+x^4+x^13 short-cycled at 8190, G2 = 1+x+x^5+x^6+x^7+x^9+x^10+x^12+x^13,
+// G1 from all ones, G2 from the per-PRN initial phase of the ICD table; chip = G1 xor G2 (1 -> +1 like the reference) ----
+bool bds_b3i_chips(int8_t* out, int prn, unsigned chip_shift)
+{
+    if (prn < 1 || prn > 63 || !load_tables()) return false;
+    // bit k = register element k of the reference's arrays (element 0 is the output, the feedback enters at element 12)
+    unsigned g1 = 0x1fff;
+    const unsigned row = static_cast<unsigned>(g_tab.b3i_phase[prn - 1]);
+    unsigned g2 = 0;
+    for (int k = 0; k < 13; k++)
+        if ((row >> (12 - k)) & 1u) g2 |= 1u << k;  // the table row is loaded in reverse order
+    std::vector<uint8_t> s1(10230), s2(10230);
+    for (int i = 0; i < 10230; i++)
+        {
+            s1[i] = g1 & 1;
+            s2[i] = g2 & 1;
+            const unsigned f1 = (g1 ^ (g1 >> 9) ^ (g1 >> 10) ^ (g1 >> 12)) & 1u;
+            const unsigned f2 = (g2 ^ (g2 >> 1) ^ (g2 >> 3) ^ (g2 >> 4) ^ (g2 >> 6) ^ (g2 >> 7) ^ (g2 >> 8) ^ (g2 >> 12)) & 1u;
+            g1 = (g1 >> 1) | (f1 << 12);
+            g2 = (g2 >> 1) | (f2 << 12);
+            if (g1 == 0x1ffcu) g1 = 0x1fff;  // 0011111111111 (elements 0 and 1 clear): restart G1
+        }
+    for (int i = 0; i < 10230; i++)
+        {
+            const int k = static_cast<int>((i + chip_shift) % 10230u);
+            out[i] = (s1[k] ^ s2[k]) ? 1 : -1;
+        }
+    return true;
+}
+
+// chips -> samples with the float32 rule of the L2C / L5 generators (gps_l2c_signal.cc:113-133, gps_l5_signal.cc:225-255):
+// index = ceil((ts * ((float)i + 1)) / tc) - 1 with a TRUE ceil, unlike sample_chips
+int sample_chips_ceil(float* dest_complex, const int8_t* chips, int code_len, double code_rate_hz, int fs)
+{
+    const int spc = static_cast<int>(static_cast<double>(fs) / (code_rate_hz / static_cast<double>(code_len)));
+    const float ts = 1.0 / static_cast<float>(fs);
+    const float tc = 1.0 / static_cast<float>(code_rate_hz);
+    for (int i = 0; i < spc; i++)
+        {
+            const int k = static_cast<int>(std::ceil((ts * (static_cast<float>(i) + 1)) / tc) - 1);
+            const int v = (i == spc - 1) ? chips[code_len - 1] : chips[k];
+            dest_complex[2 * i] = static_cast<float>(v);
+            dest_complex[2 * i + 1] = 0.0f;
+        }
+    return spc;
+}
+
+// Galileo E5a memory code of one component (0 = I, 1 = Q) as +-1
+bool galileo_e5a_component(int8_t* out, unsigned prn, int comp)
+{
+    if (prn < 1 || prn > 50 || !load_tables()) return false;
+    const uint8_t* p = g_tab.e5a_bits.data() + (static_cast<size_t>(comp) * 50 + (prn - 1)) * 1279;
+    for (int i = 0; i < 10230; i++) out[i] = ((p[i >> 3] >> (7 - (i & 7))) & 1) ? -1 : 1;
+    return true;
+}
 }  // namespace
 
 extern "C" {
@@ -326,6 +516,199 @@ gc_status gc_galileo_e1_code_gen_complex_sampled(float* dest, const char* signal
             dest[2 * d + 1] = 0.0f;
         }
     if (n_samples) *n_samples = static_cast<int32_t>(spc);
+    return GC_OK;
+}
+
+
+gc_status gc_gps_l2c_m_code_gen_float(float* dest, uint32_t prn)
+{
+    GC_REQUIRE(dest, "gc_gps_l2c_m_code_gen_float: dest is NULL");
+    std::vector<int8_t> c(10230);
+    gc_set_error("");
+    if (!gps_l2cm_chips(c.data(), prn))
+        {
+            if (!*gc_last_error()) gc_set_error("gc_gps_l2c_m_code_gen_float: PRN %u not in 1..50", prn);
+            return GC_ERR_INVALID;
+        }
+    for (int i = 0; i < 10230; i++) dest[i] = static_cast<float>(c[i]);
+    return GC_OK;
+}
+
+gc_status gc_gps_l2c_m_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, int32_t* n_samples)
+{
+    GC_REQUIRE(dest && fs > 0, "gc_gps_l2c_m_code_gen_complex_sampled: bad argument");
+    std::vector<int8_t> c(10230);
+    gc_set_error("");
+    if (!gps_l2cm_chips(c.data(), prn))
+        {
+            if (!*gc_last_error()) gc_set_error("gc_gps_l2c_m_code_gen_complex_sampled: PRN %u not in 1..50", prn);
+            return GC_ERR_INVALID;
+        }
+    const int n = sample_chips_ceil(dest, c.data(), 10230, 0.5115e6, fs);
+    if (n_samples) *n_samples = n;
+    return GC_OK;
+}
+
+static gc_status l5_float(float* dest, uint32_t prn, bool q, const char* who)
+{
+    GC_REQUIRE(dest, "%s: dest is NULL", who);
+    std::vector<int8_t> c(10230);
+    gc_set_error("");
+    if (!gps_l5_chips(c.data(), prn, q))
+        {
+            if (!*gc_last_error()) gc_set_error("%s: PRN %u not in 1..50", who, prn);
+            return GC_ERR_INVALID;
+        }
+    for (int i = 0; i < 10230; i++) dest[i] = static_cast<float>(c[i]);
+    return GC_OK;
+}
+
+static gc_status l5_sampled(float* dest, uint32_t prn, int32_t fs, int32_t* n_samples, bool q, const char* who)
+{
+    GC_REQUIRE(dest && fs > 0, "%s: bad argument", who);
+    std::vector<int8_t> c(10230);
+    gc_set_error("");
+    if (!gps_l5_chips(c.data(), prn, q))
+        {
+            if (!*gc_last_error()) gc_set_error("%s: PRN %u not in 1..50", who, prn);
+            return GC_ERR_INVALID;
+        }
+    const int n = sample_chips_ceil(dest, c.data(), 10230, 10.23e6, fs);
+    if (n_samples) *n_samples = n;
+    return GC_OK;
+}
+
+gc_status gc_gps_l5i_code_gen_float(float* dest, uint32_t prn) { return l5_float(dest, prn, false, "gc_gps_l5i_code_gen_float"); }
+gc_status gc_gps_l5q_code_gen_float(float* dest, uint32_t prn) { return l5_float(dest, prn, true, "gc_gps_l5q_code_gen_float"); }
+gc_status gc_gps_l5i_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, int32_t* n_samples)
+{
+    return l5_sampled(dest, prn, fs, n_samples, false, "gc_gps_l5i_code_gen_complex_sampled");
+}
+gc_status gc_gps_l5q_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, int32_t* n_samples)
+{
+    return l5_sampled(dest, prn, fs, n_samples, true, "gc_gps_l5q_code_gen_complex_sampled");
+}
+
+gc_status gc_beidou_b3i_code_gen_float(float* dest, int32_t prn, uint32_t chip_shift)
+{
+    GC_REQUIRE(dest, "gc_beidou_b3i_code_gen_float: dest is NULL");
+    std::vector<int8_t> c(10230);
+    gc_set_error("");
+    if (!bds_b3i_chips(c.data(), prn, chip_shift))
+        {
+            if (!*gc_last_error()) gc_set_error("gc_beidou_b3i_code_gen_float: PRN %d not in 1..63", prn);
+            return GC_ERR_INVALID;
+        }
+    for (int i = 0; i < 10230; i++) dest[i] = static_cast<float>(c[i]);
+    return GC_OK;
+}
+
+gc_status gc_beidou_b3i_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift, int32_t* n_samples)
+{
+    GC_REQUIRE(dest && fs > 0, "gc_beidou_b3i_code_gen_complex_sampled: bad argument");
+    std::vector<int8_t> c(10230);
+    gc_set_error("");
+    if (!bds_b3i_chips(c.data(), static_cast<int>(prn), chip_shift))
+        {
+            if (!*gc_last_error()) gc_set_error("gc_beidou_b3i_code_gen_complex_sampled: PRN %u not in 1..63", prn);
+            return GC_ERR_INVALID;
+        }
+    const int n = sample_chips(dest, c.data(), 10230, 10230000, fs);
+    if (n_samples) *n_samples = n;
+    return GC_OK;
+}
+
+gc_status gc_galileo_e5_a_code_gen_complex_primary(float* dest, int32_t prn, const char* signal)
+{
+    GC_REQUIRE(dest && signal, "gc_galileo_e5_a_code_gen_complex_primary: NULL argument");
+    GC_REQUIRE(signal[0] == '5' && (signal[1] == 'I' || signal[1] == 'Q' || signal[1] == 'X'),
+        "gc_galileo_e5_a_code_gen_complex_primary: signal must be \"5I\", \"5Q\" or \"5X\"");
+    std::vector<int8_t> ci(10230), cq(10230);
+    gc_set_error("");
+    if (prn < 1 || !galileo_e5a_component(ci.data(), static_cast<unsigned>(prn), 0) || !galileo_e5a_component(cq.data(), static_cast<unsigned>(prn), 1))
+        {
+            if (!*gc_last_error()) gc_set_error("gc_galileo_e5_a_code_gen_complex_primary: PRN %d not in 1..50", prn);
+            return GC_ERR_INVALID;
+        }
+    for (int i = 0; i < 10230; i++)
+        {
+            dest[2 * i] = signal[1] == 'Q' ? 0.0f : static_cast<float>(ci[i]);
+            dest[2 * i + 1] = signal[1] == 'I' ? 0.0f : static_cast<float>(cq[i]);
+        }
+    return GC_OK;
+}
+
+gc_status gc_galileo_e5_a_code_gen_complex_sampled(float* dest, const char* signal, uint32_t prn, int32_t fs, uint32_t chip_shift, int32_t* n_samples)
+{
+    GC_REQUIRE(dest && fs > 0, "gc_galileo_e5_a_code_gen_complex_sampled: bad argument");
+    std::vector<float> code(2 * 10230);
+    gc_status st = gc_galileo_e5_a_code_gen_complex_primary(code.data(), static_cast<int32_t>(prn), signal);
+    if (st != GC_OK) return st;
+    const unsigned CL = 10230;
+    const int code_freq = 10230000;
+    const unsigned spc = static_cast<unsigned>(static_cast<double>(fs) / (static_cast<double>(code_freq) / static_cast<double>(CL)));
+    const unsigned delay = ((CL - chip_shift) % CL) * spc / CL;
+    std::vector<float> re(CL), im(CL), rre, rim;
+    for (unsigned i = 0; i < CL; i++)
+        {
+            re[i] = code[2 * i];
+            im[i] = code[2 * i + 1];
+        }
+    if (fs != code_freq)
+        {
+            // resampler() picks whole complex chips: the same index for both parts
+            rre.resize(spc);
+            rim.resize(spc);
+            resample(re.data(), rre.data(), static_cast<float>(code_freq), static_cast<float>(fs), CL, spc);
+            resample(im.data(), rim.data(), static_cast<float>(code_freq), static_cast<float>(fs), CL, spc);
+            re.swap(rre);
+            im.swap(rim);
+        }
+    for (unsigned i = 0; i < spc; i++)
+        {
+            const unsigned d = (i + delay) % spc;
+            dest[2 * d] = re[i];
+            dest[2 * d + 1] = im[i];
+        }
+    if (n_samples) *n_samples = static_cast<int32_t>(spc);
+    return GC_OK;
+}
+
+gc_status gc_secondary_code(const char* signal, uint32_t prn, char* dest, int32_t capacity, int32_t* length)
+{
+    GC_REQUIRE(signal && dest && capacity > 0, "gc_secondary_code: bad argument");
+    std::string code;
+    const std::string s(signal);
+    if (s == "1C")
+        code = "0011100000001010110110010";  // Galileo E1-C CS25_1
+    else if (s == "B1" || s == "B3")
+        code = "00000100110101001110";  // BeiDou NH20 (MEO / IGSO satellites)
+    else if (s == "L5I")
+        code = "0000110101";  // GPS L5 I5 NH10
+    else if (s == "L5Q")
+        code = "00000100110101001110";  // GPS L5 Q5 NH20
+    else if (s == "5I" || s == "5Q")
+        {
+            gc_set_error("");
+            if (!load_tables())
+                {
+                    if (!*gc_last_error()) gc_set_error("gc_secondary_code: tables unavailable");
+                    return GC_ERR_INVALID;
+                }
+            if (s == "5I")
+                code = g_tab.e5a_i_secondary;
+            else
+                {
+                    GC_REQUIRE(prn >= 1 && static_cast<int>(prn) <= g_tab.n_e5a_q_secondary, "gc_secondary_code: no E5a-Q secondary code for PRN %u (1..%d)", prn,
+                        g_tab.n_e5a_q_secondary);
+                    code = g_tab.e5a_q_secondary.substr((prn - 1) * 100, 100);
+                }
+        }
+    else
+        return gc_fail(GC_ERR_INVALID, "gc_secondary_code: unknown signal \"%s\" (1C, B1, B3, L5I, L5Q, 5I, 5Q)", signal);
+    GC_REQUIRE(static_cast<int>(code.size()) + 1 <= capacity, "gc_secondary_code: capacity %d too small for %d symbols", capacity, static_cast<int>(code.size()));
+    std::memcpy(dest, code.c_str(), code.size() + 1);
+    if (length) *length = static_cast<int32_t>(code.size());
     return GC_OK;
 }
 

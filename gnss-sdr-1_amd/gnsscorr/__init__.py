@@ -213,6 +213,17 @@ API = {
     "gc_beidou_b1i_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
     "gc_galileo_e1_code_gen_sinboc11_float": (C.c_int, [_fp, C.c_char_p, C.c_uint32]),
     "gc_galileo_e1_code_gen_complex_sampled": (C.c_int, [_fp, C.c_char_p, C.c_int32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "gc_gps_l2c_m_code_gen_float": (C.c_int, [_fp, C.c_uint32]),
+    "gc_gps_l2c_m_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.POINTER(C.c_int32)]),
+    "gc_gps_l5i_code_gen_float": (C.c_int, [_fp, C.c_uint32]),
+    "gc_gps_l5q_code_gen_float": (C.c_int, [_fp, C.c_uint32]),
+    "gc_gps_l5i_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.POINTER(C.c_int32)]),
+    "gc_gps_l5q_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.POINTER(C.c_int32)]),
+    "gc_beidou_b3i_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
+    "gc_beidou_b3i_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "gc_galileo_e5_a_code_gen_complex_primary": (C.c_int, [_fp, C.c_int32, C.c_char_p]),
+    "gc_galileo_e5_a_code_gen_complex_sampled": (C.c_int, [_fp, C.c_char_p, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "gc_secondary_code": (C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
     "gc_acq_create": (C.c_int, [_vp, C.POINTER(AcqConf), C.c_int, C.POINTER(_vp)]),
     "gc_acq_destroy": (C.c_int, [_vp]),
     "gc_acq_fft_size": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -330,6 +341,69 @@ def beidou_b1i_code_gen_complex_sampled(prn, fs, chip_shift=0):
     n = C.c_int32()
     _check(load_library().gc_beidou_b1i_code_gen_complex_sampled(d.view(np.float32).ctypes.data_as(_fp), prn, fs, chip_shift, C.byref(n)))
     return d[:n.value].copy()
+
+
+def _chips10230(fn, *args):
+    d = np.zeros(10230, np.float32)
+    _check(getattr(load_library(), fn)(_f32p(d), *args))
+    return d
+
+
+def _sampled10230(fn, fs, code_rate_hz, *args):
+    d = np.zeros(int(fs / (code_rate_hz / 10230.0)) + 8, np.complex64)
+    n = C.c_int32()
+    _check(getattr(load_library(), fn)(d.view(np.float32).ctypes.data_as(_fp), *args, C.byref(n)))
+    return d[:n.value].copy()
+
+
+def gps_l2c_m_code_gen_float(prn):
+    return _chips10230("gc_gps_l2c_m_code_gen_float", prn)
+
+
+def gps_l2c_m_code_gen_complex_sampled(prn, fs):
+    return _sampled10230("gc_gps_l2c_m_code_gen_complex_sampled", fs, 0.5115e6, prn, fs)
+
+
+def gps_l5i_code_gen_float(prn):
+    return _chips10230("gc_gps_l5i_code_gen_float", prn)
+
+
+def gps_l5q_code_gen_float(prn):
+    return _chips10230("gc_gps_l5q_code_gen_float", prn)
+
+
+def gps_l5i_code_gen_complex_sampled(prn, fs):
+    return _sampled10230("gc_gps_l5i_code_gen_complex_sampled", fs, 10.23e6, prn, fs)
+
+
+def gps_l5q_code_gen_complex_sampled(prn, fs):
+    return _sampled10230("gc_gps_l5q_code_gen_complex_sampled", fs, 10.23e6, prn, fs)
+
+
+def beidou_b3i_code_gen_float(prn, chip_shift=0):
+    return _chips10230("gc_beidou_b3i_code_gen_float", prn, chip_shift)
+
+
+def beidou_b3i_code_gen_complex_sampled(prn, fs, chip_shift=0):
+    return _sampled10230("gc_beidou_b3i_code_gen_complex_sampled", fs, 10.23e6, prn, fs, chip_shift)
+
+
+def galileo_e5_a_code_gen_complex_primary(prn, signal):
+    d = np.zeros(10230, np.complex64)
+    _check(load_library().gc_galileo_e5_a_code_gen_complex_primary(d.view(np.float32).ctypes.data_as(_fp), prn, signal.encode()))
+    return d
+
+
+def galileo_e5_a_code_gen_complex_sampled(signal, prn, fs, chip_shift=0):
+    return _sampled10230("gc_galileo_e5_a_code_gen_complex_sampled", fs, 10.23e6, signal.encode(), prn, fs, chip_shift)
+
+
+def secondary_code(signal, prn=0):
+    """Secondary (overlay) code of a signal as a '0'/'1' string: "1C", "B1", "B3", "L5I", "L5Q", "5I", "5Q" (per PRN)."""
+    buf = C.create_string_buffer(128)
+    n = C.c_int32()
+    _check(load_library().gc_secondary_code(signal.encode(), prn, buf, 128, C.byref(n)))
+    return buf.value.decode()
 
 
 def galileo_e1_code_gen_sinboc11_float(signal, prn):

@@ -379,6 +379,30 @@ gc_status gc_galileo_e1_code_gen_sinboc11_float(float* dest, const char* signal,
 /* galileo_e1_code_gen_complex_sampled (…:232-255) without secondary code: 4 ms of samples at fs */
 gc_status gc_galileo_e1_code_gen_complex_sampled(float* dest, const char* signal, int32_t cboc, uint32_t prn, int32_t fs,
     uint32_t chip_shift, int32_t* n_samples);
+/* The 10.23 / 0.5115 Mcps signals.  Their per-PRN constants (IS-GPS-200 Table 3-IIa, IS-GPS-705 Table 3-Ia/Ib, BDS-SIS-ICD-B3I
+ * G2 phases, Galileo OS SIS ICD E5a memory codes) are read from data/prn_tables.bin and data/galileo_e5a_primary_codes.bin
+ * next to the library (or $GNSSCORR_DATA_DIR).  All codes are 10230 chips.
+ * gps_l2c_m_code_gen_float / _complex_sampled (src/algorithms/libs/gps_l2c_signal.cc:75-137): PRN 1..50; the sampled form
+ * holds (int)(fs / 50) complex samples (one 20 ms code) and digitises with a true ceil() */
+gc_status gc_gps_l2c_m_code_gen_float(float* dest, uint32_t prn);
+gc_status gc_gps_l2c_m_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, int32_t* n_samples);
+/* gps_l5i / gps_l5q _code_gen_float / _complex_sampled (src/algorithms/libs/gps_l5_signal.cc:197-344): PRN 1..50 */
+gc_status gc_gps_l5i_code_gen_float(float* dest, uint32_t prn);
+gc_status gc_gps_l5q_code_gen_float(float* dest, uint32_t prn);
+gc_status gc_gps_l5i_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, int32_t* n_samples);
+gc_status gc_gps_l5q_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, int32_t* n_samples);
+/* beidou_b3i_code_gen_float / _complex_sampled (src/algorithms/libs/beidou_b3i_signal_processing.cc:37-246): PRN 1..63 */
+gc_status gc_beidou_b3i_code_gen_float(float* dest, int32_t prn, uint32_t chip_shift);
+gc_status gc_beidou_b3i_code_gen_complex_sampled(float* dest, uint32_t prn, int32_t fs, uint32_t chip_shift, int32_t* n_samples);
+/* galileo_e5_a_code_gen_complex_primary / _complex_sampled (src/algorithms/libs/galileo_e5_signal_processing.cc:38-142):
+ * 10230 complex chips; signal "5I" -> (I, 0), "5Q" -> (0, Q), "5X" -> (I, Q); PRN 1..50 */
+gc_status gc_galileo_e5_a_code_gen_complex_primary(float* dest, int32_t prn, const char* signal);
+gc_status gc_galileo_e5_a_code_gen_complex_sampled(float* dest, const char* signal, uint32_t prn, int32_t fs, uint32_t chip_shift,
+    int32_t* n_samples);
+/* Secondary (overlay) code of a signal as a '0'/'1' string, the form gc_loop_sync_conf.secondary_code takes and the reference
+ * keeps in its system_parameters headers: "1C" (Galileo E1-C CS25), "B1" / "B3" (BeiDou NH20), "L5I" (NH10), "L5Q" (NH20),
+ * "5I" (Galileo E5a-I CS20), "5Q" (E5a-Q CS100 of `prn`; the reference's table holds PRN 1..47).  prn is ignored otherwise. */
+gc_status gc_secondary_code(const char* signal, uint32_t prn, char* dest, int32_t capacity, int32_t* length);
 
 /* ------------------------------------------------------------------------ */
 /* Acquisition -- PCPS (parallel code phase search), batched over satellites. */

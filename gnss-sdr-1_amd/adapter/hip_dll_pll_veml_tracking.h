@@ -1,8 +1,8 @@
 /*!
  * \file hip_dll_pll_veml_tracking.h
  * \brief Image of the dll_pll_veml_tracking block
- * (src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.{h,cc}) for the three signals of the
- * hot path (GPS L1 C/A "1C", Galileo E1 "1B", BeiDou B1I "B1"), with the correlations done by
+ * (src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.{h,cc}) for GPS L1 C/A "1C", L2C(M) "2S", L5 "L5",
+ * Galileo E1 "1B", E5a "5X", BeiDou B1I "B1" and B3I "B3", with the correlations done by
  * Hip_Multicorrelator_Real_Codes (libgnsscorr.so, MI355X).
  *
  * Mirrored: constructor set-up of taps/shifts and of the per-signal synchronisation data (dll_pll_veml_tracking.cc:113-440),
@@ -83,6 +83,58 @@ public:
                 d_symbols_per_bit = 20;  // BEIDOU_B1I_TELEMETRY_SYMBOLS_PER_BIT
                 d_secondary = true;
                 d_secondary_code_string = "00000100110101001110";  // BEIDOU_B1I_SECONDARY_CODE_STR (NH20)
+                trk_parameters.track_pilot = false;
+            }
+        else if (trk_parameters.system == 'G' && signal_type == "2S")
+            {
+                d_signal_carrier_freq = 1.22760e9;  // GPS_L2_FREQ_HZ
+                d_code_period = 0.02;               // GPS_L2_M_PERIOD
+                d_code_chip_rate = 0.5115e6;
+                d_code_length_chips = 10230;
+                d_symbols_per_bit = 1;  // GPS_L2_SAMPLES_PER_SYMBOL
+                d_correlation_length_ms = 20;
+                d_code_samples_per_chip = 1;
+                trk_parameters.track_pilot = false;  // no pilot component, no secondary code
+            }
+        else if (trk_parameters.system == 'G' && signal_type == "L5")
+            {
+                d_signal_carrier_freq = 1.17645e9;  // GPS_L5_FREQ_HZ
+                d_code_period = 0.001;
+                d_code_chip_rate = 10.23e6;
+                d_symbols_per_bit = 10;  // GPS_L5_SAMPLES_PER_SYMBOL
+                d_correlation_length_ms = 1;
+                d_code_samples_per_chip = 1;
+                d_code_length_chips = 10230;
+                d_secondary = true;
+                // pilot: Q5 with NH20, in quadrature with the data component; data: I5 with NH10
+                d_secondary_code_string = trk_parameters.track_pilot ? "00000100110101001110" : "0000110101";
+                interchange_iq = trk_parameters.track_pilot;
+            }
+        else if (trk_parameters.system == 'E' && signal_type == "5X")
+            {
+                d_signal_carrier_freq = 1.17645e9;  // GALILEO_E5A_FREQ_HZ
+                d_code_period = 0.001;
+                d_code_chip_rate = 1.023e7;
+                d_symbols_per_bit = 20;
+                d_correlation_length_ms = 1;
+                d_code_samples_per_chip = 1;
+                d_code_length_chips = 10230;
+                // pilot: E5a-Q with the 100-symbol secondary code of the PRN (set in start_tracking); on the data component the
+                // secondary code is left to the telemetry decoder
+                d_secondary = trk_parameters.track_pilot;
+                interchange_iq = trk_parameters.track_pilot;
+            }
+        else if (trk_parameters.system == 'C' && signal_type == "B3")
+            {
+                d_signal_carrier_freq = 1.268520e9;  // BEIDOU_B3I_FREQ_HZ
+                d_code_period = 0.001;
+                d_code_chip_rate = 10.23e6;
+                d_code_length_chips = 10230;
+                d_symbols_per_bit = 20;
+                d_correlation_length_ms = 1;
+                d_code_samples_per_chip = 1;
+                d_secondary = true;
+                d_secondary_code_string = "00000100110101001110";  // BEIDOU_B3I_SECONDARY_CODE_STR (NH20)
                 trk_parameters.track_pilot = false;
             }
         if (trk_parameters.extend_correlation_symbols > 1)
@@ -202,7 +254,55 @@ public:
         d_code_ph_history.clear();
         d_carrier_loop_filter.initialize(static_cast<float>(d_acq_carrier_doppler_hz));
         d_code_loop_filter.initialize();
-        if (trk_parameters.system == 'G')
+        const uint32_t prn = d_acquisition_gnss_synchro->PRN;
+        if (trk_parameters.system == 'G' && signal_type == "2S")
+            gc_gps_l2c_m_code_gen_float(d_tracking_code.data(), prn);
+        else if (trk_parameters.system == 'G' && signal_type == "L5")
+            {
+                if (trk_parameters.track_pilot)
+                    {
+                        gc_gps_l5q_code_gen_float(d_tracking_code.data(), prn);
+                        gc_gps_l5i_code_gen_float(d_data_code.data(), prn);
+                        d_Prompt_Data = gr_complex(0.0, 0.0);
+                        correlator_data_cpu.set_local_code_and_taps(d_code_length_chips, d_data_code.data(), &d_local_code_shift_chips[1]);
+                    }
+                else
+                    gc_gps_l5i_code_gen_float(d_tracking_code.data(), prn);
+            }
+        else if (trk_parameters.system == 'E' && signal_type == "5X")
+            {
+                // the complex primary code holds E5a-I in the real and E5a-Q in the imaginary part (:606-626)
+                std::vector<float> aux(2 * d_code_length_chips);
+                gc_galileo_e5_a_code_gen_complex_primary(aux.data(), static_cast<int32_t>(prn), "5X");
+                if (trk_parameters.track_pilot)
+                    {
+                        char sec[128];
+                        int32_t len = 0;
+                        if (gc_secondary_code("5Q", prn, sec, sizeof sec, &len) == GC_OK) d_secondary_code_string.assign(sec, len);
+                        for (uint32_t i = 0; i < d_code_length_chips; i++)
+                            {
+                                d_tracking_code[i] = aux[2 * i + 1];
+                                d_data_code[i] = aux[2 * i];
+                            }
+                        d_Prompt_Data = gr_complex(0.0, 0.0);
+                        correlator_data_cpu.set_local_code_and_taps(d_code_length_chips, d_data_code.data(), &d_local_code_shift_chips[1]);
+                    }
+                else
+                    for (uint32_t i = 0; i < d_code_length_chips; i++) d_tracking_code[i] = aux[2 * i];
+            }
+        else if (trk_parameters.system == 'C' && signal_type == "B3")
+            {
+                gc_beidou_b3i_code_gen_float(d_tracking_code.data(), static_cast<int32_t>(prn), 0);
+                if (prn > 0 and prn < 6)
+                    {
+                        // GEO satellites broadcast D2 (:672-705)
+                        d_symbols_per_bit = 2;
+                        d_secondary = false;
+                        d_secondary_code_string.clear();
+                        set_preamble({1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 0}, 2);
+                    }
+            }
+        else if (trk_parameters.system == 'G')
             gc_gps_l1_ca_code_gen_float(d_tracking_code.data(), static_cast<int32_t>(d_acquisition_gnss_synchro->PRN), 0);
         else if (trk_parameters.system == 'E')
             {
@@ -458,13 +558,14 @@ private:
         d_VE_accu = d_E_accu = d_P_accu = d_L_accu = d_VL_accu = gr_complex(0.0, 0.0);
     }
 
-    //! what every valid period hands to the telemetry decoder (:1693-1725, :1789-1817, :1847-1878); E1-B and E1-C are in
-    //! anti-phase, not in quadrature, so I and Q are never interchanged for the signals mirrored here
+    //! what every valid period hands to the telemetry decoder (:1693-1725, :1789-1817, :1847-1878).  GPS L5 and Galileo E5a
+    //! carry data and pilot in quadrature: with the loop on the pilot, I and Q of the data prompt are interchanged; E1-B and
+    //! E1-C are in anti-phase and are not.
     void fill_synchro(Gnss_Synchro& d) const
     {
         const gr_complex p = trk_parameters.track_pilot ? d_Prompt_Data : d_correlator_outs[d_veml ? 2 : 1];
-        d.Prompt_I = static_cast<double>(p.real());
-        d.Prompt_Q = static_cast<double>(p.imag());
+        d.Prompt_I = static_cast<double>(interchange_iq ? p.imag() : p.real());
+        d.Prompt_Q = static_cast<double>(interchange_iq ? p.real() : p.imag());
         d.Code_phase_samples = d_rem_code_phase_samples;
         d.Carrier_phase_rads = d_acc_carrier_phase_rad;
         d.Carrier_Doppler_hz = d_carrier_doppler_hz;
@@ -664,8 +765,8 @@ private:
                 for (int i = 0; i < 5; i++) f[i] *= scale_factor;
             }
         const gr_complex p = trk_parameters.track_pilot ? d_Prompt_Data : d_correlator_outs[d_veml ? 2 : 1];
-        f[5] = p.real();  // prompt I
-        f[6] = p.imag();  // prompt Q
+        f[5] = interchange_iq ? p.imag() : p.real();  // prompt I
+        f[6] = interchange_iq ? p.real() : p.imag();  // prompt Q
         put(f, sizeof f);
         uint64_t stamp = d_sample_counter + static_cast<uint64_t>(d_current_prn_length_samples);
         put(&stamp, sizeof stamp);
@@ -744,6 +845,7 @@ private:
     std::vector<float> d_data_code;
     gr_complex d_Prompt_Data;
     bool d_secondary = false;
+    bool interchange_iq = false;
     bool d_enable_extended_integration = false;
     std::string d_secondary_code_string;
     std::vector<int32_t> d_preambles_symbols;

@@ -52,6 +52,7 @@ struct Component
 {
     std::vector<float> code;
     std::vector<float> symbols;
+    bool quadrature = false;  // the component rides on j * carrier (GPS L5 Q5, Galileo E5a-Q)
 };
 static std::vector<gr_complex> synth_symbols(const std::vector<Component>& comps, double chip_rate_hz, double carrier_hz, double fs, size_t n, double fd,
     double delay_samples, double cn0_dbhz, unsigned seed, double phi = 0.7)
@@ -68,9 +69,10 @@ static std::vector<gr_complex> synth_symbols(const std::vector<Component>& comps
             const double ph = 2.0 * M_PI * fd * static_cast<double>(i) / fs + phi;
             const size_t k = static_cast<size_t>(std::floor(tau0 + static_cast<double>(i) * rate));
             const size_t chip = k % L, period = k / L;
-            double v = 0.0;
-            for (const auto& c : comps) v += c.code[chip] * c.symbols[period % c.symbols.size()];
-            x[i] = gr_complex(static_cast<float>(amp * v * std::cos(ph)) + nd(gen), static_cast<float>(amp * v * std::sin(ph)) + nd(gen));
+            double vi = 0.0, vq = 0.0;
+            for (const auto& c : comps) (c.quadrature ? vq : vi) += c.code[chip] * c.symbols[period % c.symbols.size()];
+            const double cs = std::cos(ph), sn = std::sin(ph);
+            x[i] = gr_complex(static_cast<float>(amp * (vi * cs - vq * sn)) + nd(gen), static_cast<float>(amp * (vi * sn + vq * cs)) + nd(gen));
         }
     return x;
 }
@@ -401,6 +403,191 @@ static void test_gps_bit_synchronisation()
     EXPECT(synced == 1, "GPS: %d of 2 polarities synchronised", synced);
 }
 
+// Pilot tracking of a signal whose data and pilot components are in quadrature (GPS L5: I5 data x NH10, Q5 pilot x NH20;
+// Galileo E5a: E5a-I data x CS20, E5a-Q pilot x CS100 of the PRN): secondary-code lock on the pilot, extended integration,
+// data symbols from the interchanged data prompt (interchange_iq).
+template <class Trk>
+static void pilot_quadrature_case(const char* name, const char* role, char system, const char* signal, uint32_t prn, const std::vector<float>& data_code,
+    const std::vector<float>& pilot_code, const std::string& data_secondary, const std::string& pilot_secondary, double carrier_hz, unsigned seed)
+{
+    const double fs = 25e6, fd = -3100.0, cn0 = 48.0, delay_samples = 7777.0;
+    Component d, p;
+    d.code = data_code;
+    p.code = pilot_code;
+    p.quadrature = true;
+    std::mt19937 gen(seed);
+    // one data bit per data-secondary-code period
+    const size_t n_periods = pilot_secondary.size() * 2 + 70;
+    float bit = 1.0f;
+    for (size_t k = 0; k < n_periods + 4; k++)
+        {
+            if (k % data_secondary.size() == 0) bit = (gen() & 1u) ? 1.0f : -1.0f;
+            d.symbols.push_back(bit * (data_secondary[k % data_secondary.size()] == '0' ? 1.0f : -1.0f));
+        }
+    for (char ch : pilot_secondary) p.symbols.push_back(ch == '0' ? 1.0f : -1.0f);
+    auto x = synth_symbols({d, p}, 10.23e6, carrier_hz, fs, 25000 * n_periods, fd, delay_samples, cn0, seed + 100);
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "25000000");
+    config.set_property(std::string(role) + ".track_pilot", "true");
+    config.set_property(std::string(role) + ".extend_correlation_symbols", "5");
+    config.set_property(std::string(role) + ".pll_bw_hz", "40.0");
+    config.set_property(std::string(role) + ".dll_bw_hz", "2.0");
+    config.set_property(std::string(role) + ".pll_bw_narrow_hz", "12.0");
+    config.set_property(std::string(role) + ".dll_bw_narrow_hz", "1.0");
+    config.set_property(std::string(role) + ".early_late_space_narrow_chips", "0.4");
+    config.set_property(std::string(role) + ".pull_in_time_s", "0");
+    Gnss_Synchro syn;
+    syn.System = system;
+    syn.Signal[0] = signal[0];
+    syn.Signal[1] = signal[1];
+    syn.PRN = prn;
+    syn.Acq_delay_samples = delay_samples;
+    syn.Acq_doppler_hz = fd + 2.0;
+    syn.Acq_samplestamp_samples = 0;
+    Trk trk(&config, role, 1, 1);
+    EXPECT(trk.conf().track_pilot && trk.conf().extend_correlation_symbols == 5 && trk.conf().vector_length == 25000, "%s: configuration", name);
+    trk.set_gnss_synchro(&syn);
+    trk.start_tracking();
+    auto blk = trk.block();
+    size_t pos = 0;
+    int epochs = 0, first_ext = -1, agree = 0, counted = 0;
+    Gnss_Synchro out;
+    while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+        {
+            int produced = 0;
+            const int st_in = blk->state();
+            pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+            if (st_in < 2) continue;
+            if (blk->state() >= 3 && first_ext < 0) first_ext = epochs;
+            if (first_ext >= 0 && epochs > first_ext + 30 && produced)
+                {
+                    counted++;
+                    if ((out.Prompt_I > 0) == (d.symbols[(epochs + 2) % d.symbols.size()] > 0)) agree++;
+                }
+            epochs++;
+        }
+    EXPECT(blk->last_status() == GC_OK, "%s: engine status %d (%s)", name, blk->last_status(), gc_last_error());
+    EXPECT(blk->state() == 3 || blk->state() == 4, "%s: state %d", name, blk->state());
+    // the first complete pilot secondary code the loop sees ends at stream period 2 * length - 1 = epoch 2 * length - 3
+    EXPECT(first_ext == static_cast<int>(2 * pilot_secondary.size()) - 3, "%s: secondary code locked at epoch %d", name, first_ext);
+    EXPECT(counted > 20 && (agree == counted || agree == 0), "%s: %d of %d data symbols agree", name, agree, counted);
+    EXPECT(std::fabs(blk->carrier_doppler_hz() - fd) < 6.0 && blk->events().empty(), "%s: Doppler %.2f", name, blk->carrier_doppler_hz());
+    std::printf("%s: secondary code (%zu symbols) locked at epoch %d, %d / %d data symbols on the interchanged prompt, Doppler %.2f Hz, C/N0 %.1f dB-Hz\n", name,
+        pilot_secondary.size(), first_ext, agree, counted, blk->carrier_doppler_hz(), blk->cn0_db_hz());
+}
+
+static void test_gps_l5_pilot()
+{
+    std::vector<float> i5(10230), q5(10230);
+    gc_gps_l5i_code_gen_float(i5.data(), 7);
+    gc_gps_l5q_code_gen_float(q5.data(), 7);
+    pilot_quadrature_case<GpsL5DllPllTrackingHip>("GPS L5 pilot tracking", "Tracking_L5", 'G', "L5", 7, i5, q5, "0000110101", "00000100110101001110", 1.17645e9, 31);
+}
+
+static void test_galileo_e5a_pilot()
+{
+    std::vector<float> x(2 * 10230), i5(10230), q5(10230);
+    gc_galileo_e5_a_code_gen_complex_primary(x.data(), 3, "5X");
+    for (int i = 0; i < 10230; i++)
+        {
+            i5[i] = x[2 * i];
+            q5[i] = x[2 * i + 1];
+        }
+    char sec[128];
+    int32_t len = 0;
+    EXPECT(gc_secondary_code("5Q", 3, sec, sizeof sec, &len) == GC_OK && len == 100, "E5a-Q secondary code");
+    pilot_quadrature_case<GalileoE5aDllPllTrackingHip>("Galileo E5a pilot tracking", "Tracking_5X", 'E', "5X", 3, i5, q5, "10000100001011101001", std::string(sec, 100),
+        1.17645e9, 32);
+}
+
+static void test_beidou_b3i_and_gps_l2c()
+{
+    {
+        // B3I: NH20 on the data component, 10.23 Mcps
+        const double fs = 25e6, fd = 1234.0, delay_samples = 4321.0;
+        Component d;
+        d.code.resize(10230);
+        gc_beidou_b3i_code_gen_float(d.code.data(), 20, 0);
+        for (char ch : std::string("00000100110101001110")) d.symbols.push_back(ch == '0' ? 1.0f : -1.0f);
+        auto x = synth_symbols({d}, 10.23e6, 1.268520e9, fs, 25000 * 120, fd, delay_samples, 47.0, 41);
+        InMemoryConfiguration config;
+        config.set_property("GNSS-SDR.internal_fs_sps", "25000000");
+        config.set_property("Tracking_B3.pull_in_time_s", "0");
+        Gnss_Synchro syn;
+        syn.System = 'C';
+        syn.Signal[0] = 'B';
+        syn.Signal[1] = '3';
+        syn.PRN = 20;
+        syn.Acq_delay_samples = delay_samples;
+        syn.Acq_doppler_hz = fd - 3.0;
+        syn.Acq_samplestamp_samples = 0;
+        BeidouB3iDllPllTrackingHip trk(&config, "Tracking_B3", 1, 1);
+        EXPECT(trk.implementation() == "BEIDOU_B3I_DLL_PLL_Tracking_HIP" && trk.conf().vector_length == 25000, "B3I adapter");
+        trk.set_gnss_synchro(&syn);
+        trk.start_tracking();
+        auto blk = trk.block();
+        size_t pos = 0;
+        int epochs = 0, first4 = -1;
+        Gnss_Synchro out;
+        while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+            {
+                int produced = 0;
+                const int st_in = blk->state();
+                pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+                if (st_in < 2) continue;
+                if (blk->state() == 4 && first4 < 0) first4 = epochs;
+                epochs++;
+            }
+        EXPECT(first4 == 37 && blk->state() == 4, "B3I: NH20 locked at epoch %d, state %d", first4, blk->state());
+        EXPECT(std::fabs(blk->carrier_doppler_hz() - fd) < 5.0 && blk->events().empty(), "B3I: Doppler %.2f", blk->carrier_doppler_hz());
+        std::printf("BeiDou B3I: NH20 locked at epoch %d, Doppler %.2f Hz, C/N0 %.1f dB-Hz\n", first4, blk->carrier_doppler_hz(), blk->cn0_db_hz());
+    }
+    {
+        // L2C(M): one 20 ms code per symbol -> narrow tracking (state 4) from the first loop update
+        const double fs = 2.046e6, fd = -800.0, delay_samples = 12345.0;
+        Component d;
+        d.code.resize(10230);
+        gc_gps_l2c_m_code_gen_float(d.code.data(), 12);
+        d.symbols = {1.0f, -1.0f, -1.0f, 1.0f, -1.0f};
+        auto x = synth_symbols({d}, 0.5115e6, 1.22760e9, fs, 40920 * 60, fd, delay_samples, 42.0, 42);
+        InMemoryConfiguration config;
+        config.set_property("GNSS-SDR.internal_fs_sps", "2046000");
+        config.set_property("Tracking_2S.pull_in_time_s", "0");
+        config.set_property("Tracking_2S.extend_correlation_symbols", "4");  // not allowed on L2C(M): forced to 1
+        Gnss_Synchro syn;
+        syn.System = 'G';
+        syn.Signal[0] = '2';
+        syn.Signal[1] = 'S';
+        syn.PRN = 12;
+        syn.Acq_delay_samples = delay_samples;
+        syn.Acq_doppler_hz = fd + 1.0;
+        syn.Acq_samplestamp_samples = 0;
+        GpsL2MDllPllTrackingHip trk(&config, "Tracking_2S", 1, 1);
+        EXPECT(trk.conf().vector_length == 40920 && trk.conf().extend_correlation_symbols == 1, "L2C adapter: %u samples, extension %d", trk.conf().vector_length,
+            trk.conf().extend_correlation_symbols);
+        trk.set_gnss_synchro(&syn);
+        trk.start_tracking();
+        auto blk = trk.block();
+        size_t pos = 0;
+        int epochs = 0, agree = 0;
+        Gnss_Synchro out;
+        while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+            {
+                int produced = 0;
+                const int st_in = blk->state();
+                pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+                if (st_in < 2) continue;
+                if (produced && epochs > 20 && (out.Prompt_I > 0) == (d.symbols[(epochs + 2) % d.symbols.size()] > 0)) agree++;
+                epochs++;
+            }
+        EXPECT(blk->state() == 4 && blk->events().empty(), "L2C: state %d", blk->state());
+        EXPECT(std::fabs(blk->carrier_doppler_hz() - fd) < 1.0, "L2C: Doppler %.2f", blk->carrier_doppler_hz());
+        EXPECT(agree == epochs - 21 || agree == 0, "L2C: %d of %d symbols", agree, epochs - 21);
+        std::printf("GPS L2C(M): %d 20 ms periods in state 4, Doppler %.2f Hz, C/N0 %.1f dB-Hz, symbols %d / %d\n", epochs, blk->carrier_doppler_hz(), blk->cn0_db_hz(),
+            agree, epochs - 21);
+    }
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -443,6 +630,9 @@ int main()
     test_galileo_pilot_extended();
     test_beidou_secondary_lock();
     test_gps_bit_synchronisation();
+    test_gps_l5_pilot();
+    test_galileo_e5a_pilot();
+    test_beidou_b3i_and_gps_l2c();
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <fstream>
 #include <string>
+#include <random>
 #include <vector>
 
 static int g_fail = 0;
@@ -422,6 +423,75 @@ static void test_beidou_sizes()
     std::printf("BeiDou B1I acquisition: delay %g samples, Doppler %g Hz\n", gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz);
 }
 
+// The 10.23 / 0.5115 Mcps signals: a delayed, Doppler-shifted replica in noise is found where it was put.
+template <class Adapter>
+static void wideband_case(const char* name, const char* role, char system, const char* signal, uint32_t prn, int64_t fs, unsigned expect_samples, unsigned expect_fft,
+    int delay, float doppler, const std::vector<gr_complex>& code_one_period, const char* extra_key = nullptr)
+{
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", std::to_string(fs));
+    if (extra_key) config.set_property(std::string(role) + "." + extra_key, "true");
+    Gnss_Synchro gnss_synchro;
+    gnss_synchro.System = system;
+    gnss_synchro.Signal[0] = signal[0];
+    gnss_synchro.Signal[1] = signal[1];
+    gnss_synchro.PRN = prn;
+    Adapter acquisition(&config, role, 1, 0);
+    acquisition.set_gnss_synchro(&gnss_synchro);
+    acquisition.set_doppler_max(5000);
+    acquisition.set_doppler_step(250);
+    acquisition.set_threshold(0.002f);
+    acquisition.init();
+    acquisition.set_local_code();
+    auto blk = acquisition.block();
+    EXPECT(blk->consumed_samples() == expect_samples && blk->fft_size() == expect_fft, "%s sizes %u %u", name, blk->consumed_samples(), blk->fft_size());
+    EXPECT(blk->last_status() == GC_OK, "%s: engine status %d: %s", name, blk->last_status(), gc_last_error());
+    const int n_code = static_cast<int>(code_one_period.size());
+    std::vector<gr_complex> x(expect_samples + 5000);
+    std::mt19937 gen(99);
+    std::normal_distribution<float> nd(0.0f, 2.0f);  // -9 dB per sample
+    for (size_t n = 0; n < x.size(); n++)
+        {
+            const gr_complex c = code_one_period[(static_cast<int>(n) - delay + 4 * n_code) % n_code];
+            // the receiver sees the real part of I + jQ modulated on the carrier: here simply the complex baseband replica
+            x[n] = c * std::exp(gr_complex(0.0f, 2.0f * 3.14159265f * doppler * static_cast<float>(n) / static_cast<float>(fs))) + gr_complex(nd(gen), nd(gen));
+        }
+    acquisition.set_state(1);
+    run_flowgraph(acquisition, x, 5000);
+    EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "%s ACQ SUCCESS", name);
+    EXPECT(std::abs(gnss_synchro.Acq_delay_samples - delay) <= 1.0 && std::abs(gnss_synchro.Acq_doppler_hz - doppler) <= 125.0, "%s delay %g Doppler %g", name,
+        gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz);
+    std::printf("%s acquisition: delay %g samples (truth %d), Doppler %g Hz (truth %g)\n", name, gnss_synchro.Acq_delay_samples, delay, gnss_synchro.Acq_doppler_hz, doppler);
+}
+
+static void test_wideband_acquisition()
+{
+    const int64_t fs = 25000000;
+    std::vector<gr_complex> code(25008);
+    gc_gps_l5i_code_gen_complex_sampled(reinterpret_cast<float*>(code.data()), 7, fs, nullptr);
+    code.resize(25000);
+    wideband_case<GpsL5iPcpsAcquisitionHip>("GPS L5I", "Acquisition_L5", 'G', "L5", 7, fs, 25000, 25000, 9876, -1750.0f, code);
+    code.assign(25008, gr_complex());
+    gc_beidou_b3i_code_gen_complex_sampled(reinterpret_cast<float*>(code.data()), 20, fs, 0, nullptr);
+    code.resize(25000);
+    // like B1I the adapter leaves ms_per_code at 0: the block doubles the FFT
+    wideband_case<BeidouB3iPcpsAcquisitionHip>("BeiDou B3I", "Acquisition_B3", 'C', "B3", 20, fs, 25000, 50000, 12345, 2250.0f, code);
+    code.assign(25008, gr_complex());
+    gc_galileo_e5_a_code_gen_complex_sampled(reinterpret_cast<float*>(code.data()), "5X", 3, fs, 0, nullptr);
+    code.resize(25000);
+    wideband_case<GalileoE5aPcpsAcquisitionHip>("Galileo E5a (I+Q)", "Acquisition_5X", 'E', "5X", 3, fs, 25000, 25000, 222, 500.0f, code, "acquire_iq");
+    {
+        // pilot-only replica against the full I + jQ signal: half the power, same peak
+        wideband_case<GalileoE5aPcpsAcquisitionHip>("Galileo E5a (pilot)", "Acquisition_5X", 'E', "5X", 3, fs, 25000, 25000, 222, 500.0f, code, "acquire_pilot");
+    }
+    // L2C(M): one 20 ms code = 40920 samples at 2.046 Msps
+    const int64_t fs2 = 2046000;
+    code.assign(40928, gr_complex());
+    gc_gps_l2c_m_code_gen_complex_sampled(reinterpret_cast<float*>(code.data()), 12, fs2, nullptr);
+    code.resize(40920);
+    wideband_case<GpsL2MPcpsAcquisitionHip>("GPS L2C(M)", "Acquisition_2S", 'G', "2S", 12, fs2, 40920, 40920, 31000, -250.0f, code);
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2)
@@ -442,6 +512,7 @@ int main(int argc, char** argv)
     test_galileo_acquisition(argv[1]);
     test_glonass_acquisition(argv[1]);
     test_beidou_sizes();
+    test_wideband_acquisition();
     std::printf(g_fail ? "%d FAILURES\n" : "adapter self-test passed\n", g_fail);
     return g_fail ? 1 : 0;
 }

@@ -1,12 +1,14 @@
 /*!
  * \file pcps_acquisition_adapters.h
- * \brief AcquisitionInterface adapters for the three signals of the hot path, backed by hip_pcps_acquisition.
+ * \brief AcquisitionInterface adapters (GPS L1 C/A, L2C(M), L5I; Galileo E1, E5a; BeiDou B1I, B3I; GLONASS L1 C/A) backed by
+ * hip_pcps_acquisition.
  *
  * Configuration keys, derived sizes, local-code generation and the Pfa -> threshold rule follow
  *   GpsL1CaPcpsAcquisition           src/algorithms/acquisition/adapters/gps_l1_ca_pcps_acquisition.cc:46-358
  *   GalileoE1PcpsAmbiguousAcquisition src/algorithms/acquisition/adapters/galileo_e1_pcps_ambiguous_acquisition.cc:46-330
  *   BeidouB1iPcpsAcquisition          src/algorithms/acquisition/adapters/beidou_b1i_pcps_acquisition.cc:45-330
  *   GlonassL1CaPcpsAcquisition        src/algorithms/acquisition/adapters/glonass_l1_ca_pcps_acquisition.cc:44-330
+ *   GpsL2MPcpsAcquisition, GpsL5iPcpsAcquisition, GalileoE5aPcpsAcquisition, BeidouB3iPcpsAcquisition (same directory)
  * (item_type gr_complex only; `dump` / `dump_filename` / `dump_channel` write the reference's .mat
  * variables, see hip_pcps_acquisition::dump_results; the acquisition resampler and the GNU Radio
  * connect()/get_left_block() plumbing are outside this path).  Registration in a GNSS-SDR tree is one
@@ -29,7 +31,11 @@ enum class AcqSignal
     GPS_L1_CA,
     GALILEO_E1,
     BEIDOU_B1I,
-    GLONASS_L1_CA
+    GLONASS_L1_CA,
+    GPS_L2_M,
+    GPS_L5I,
+    GALILEO_E5A,
+    BEIDOU_B3I
 };
 
 // constants of GPS_L1_CA.h:54-61, Galileo_E1.h:55-60, Beidou_B1I.h:52-56
@@ -53,6 +59,14 @@ inline AcqSignalTraits acq_traits(AcqSignal s)
             return {2.046e6, 2046.0, 4.8875e-07, 0.001, 1, "BEIDOU_B1I_PCPS_Acquisition_HIP"};
         case AcqSignal::GLONASS_L1_CA:
             return {0.511e6, 511.0, 1.9569e-06, 0.001, 1, "GLONASS_L1_CA_PCPS_Acquisition_HIP"};  // GLONASS_L1_L2_CA.h:93-97
+        case AcqSignal::GPS_L2_M:
+            return {0.5115e6, 10230.0, 1.0 / 0.5115e6, 0.02, 20, "GPS_L2_M_PCPS_Acquisition_HIP"};  // GPS_L2C.h:56-58
+        case AcqSignal::GPS_L5I:
+            return {10.23e6, 10230.0, 1.0 / 10.23e6, 0.001, 1, "GPS_L5i_PCPS_Acquisition_HIP"};  // GPS_L5.h:54-57
+        case AcqSignal::GALILEO_E5A:
+            return {1.023e7, 10230.0, 1.0 / 1.023e7, 0.001, 1, "Galileo_E5a_Pcps_Acquisition_HIP"};  // Galileo_E5a.h:44-51
+        case AcqSignal::BEIDOU_B3I:
+            return {10.23e6, 10230.0, 1.0 / 10.23e6, 0.001, 1, "BEIDOU_B3I_PCPS_Acquisition_HIP"};  // Beidou_B3I.h:41-44
         default:
             return {1.023e6, 1023.0, 9.7752e-07, 0.001, 1, "GPS_L1_CA_PCPS_Acquisition_HIP"};
         }
@@ -119,6 +133,47 @@ public:
                 vector_length_ = sampled_ms_ * acq_parameters_.samples_per_ms;
                 if (acq_parameters_.bit_transition_flag) vector_length_ *= 2;
             }
+        else if (SIG == AcqSignal::GPS_L2_M)
+            {
+                // gps_l2_m_pcps_acquisition.cc:81-128,155: whole 20 ms codes
+                acq_parameters_.ms_per_code = 20;
+                sampled_ms_ = configuration_->property(role + ".coherent_integration_time_ms", acq_parameters_.ms_per_code);
+                if ((sampled_ms_ % acq_parameters_.ms_per_code) != 0) sampled_ms_ = acq_parameters_.ms_per_code;
+                acq_parameters_.sampled_ms = sampled_ms_;
+                code_length_ = static_cast<unsigned int>(std::floor(static_cast<double>(fs_in_) / (t.code_rate_hz / t.code_length_chips)));
+                acq_parameters_.samples_per_ms = static_cast<float>(fs_in_) * 0.001;
+                acq_parameters_.samples_per_chip = static_cast<unsigned int>(std::ceil((1.0 / t.code_rate_hz) * static_cast<float>(acq_parameters_.fs_in)));
+                acq_parameters_.samples_per_code = acq_parameters_.samples_per_ms * static_cast<float>(t.code_period_s * 1000.0);
+                vector_length_ = acq_parameters_.sampled_ms * acq_parameters_.samples_per_ms * (acq_parameters_.bit_transition_flag ? 2 : 1);
+            }
+        else if (SIG == AcqSignal::GPS_L5I)
+            {
+                // gps_l5i_pcps_acquisition.cc:82-135
+                sampled_ms_ = configuration_->property(role + ".coherent_integration_time_ms", 1);
+                acq_parameters_.sampled_ms = sampled_ms_;
+                acq_parameters_.ms_per_code = 1;
+                code_length_ = static_cast<unsigned int>(std::floor(static_cast<double>(fs_in_) / (t.code_rate_hz / t.code_length_chips)));
+                acq_parameters_.samples_per_ms = static_cast<float>(fs_in_) * 0.001;
+                acq_parameters_.samples_per_chip = static_cast<unsigned int>(std::ceil((1.0 / t.code_rate_hz) * static_cast<float>(acq_parameters_.fs_in)));
+                acq_parameters_.samples_per_code = acq_parameters_.samples_per_ms * static_cast<float>(t.code_period_s * 1000.0);
+                vector_length_ = std::floor(acq_parameters_.sampled_ms * acq_parameters_.samples_per_ms) * (acq_parameters_.bit_transition_flag ? 2 : 1);
+            }
+        else if (SIG == AcqSignal::GALILEO_E5A)
+            {
+                // galileo_e5a_pcps_acquisition.cc:60-144: 1 ms, data (5I), pilot (5Q) or both components (5X) in the replica
+                acquire_pilot_ = configuration_->property(role + ".acquire_pilot", false);
+                acquire_iq_ = configuration_->property(role + ".acquire_iq", false);
+                if (acquire_iq_) acquire_pilot_ = false;
+                sampled_ms_ = 1;
+                acq_parameters_.sampled_ms = sampled_ms_;
+                acq_parameters_.ms_per_code = 1;
+                acq_parameters_.samples_per_ms = static_cast<float>(fs_in_) * 0.001;
+                acq_parameters_.samples_per_chip = static_cast<unsigned int>(std::ceil((1.0 / t.code_rate_hz) * static_cast<float>(acq_parameters_.fs_in)));
+                code_length_ = static_cast<unsigned int>(std::round(static_cast<double>(fs_in_) / t.code_rate_hz * t.code_length_chips));
+                vector_length_ = code_length_ * sampled_ms_;
+                if (acq_parameters_.bit_transition_flag) vector_length_ *= 2;
+                acq_parameters_.samples_per_code = acq_parameters_.samples_per_ms * 1.0f;
+            }
         else if (SIG == AcqSignal::GLONASS_L1_CA)
             {
                 // glonass_l1_ca_pcps_acquisition.cc:62-113
@@ -134,7 +189,8 @@ public:
             }
         else
             {
-                // beidou_b1i_pcps_acquisition.cc:73-104: ms_per_code and samples_per_chip keep Acq_Conf's zeros
+                // beidou_b1i_pcps_acquisition.cc:73-104, beidou_b3i_pcps_acquisition.cc:71-104: ms_per_code and samples_per_chip keep
+                // Acq_Conf's zeros
                 sampled_ms_ = configuration_->property(role + ".coherent_integration_time_ms", 1);
                 acq_parameters_.sampled_ms = sampled_ms_;
                 code_length_ = static_cast<uint32_t>(std::round(static_cast<double>(fs_in_) / (t.code_rate_hz / t.code_length_chips)));
@@ -202,6 +258,21 @@ public:
             gc_beidou_b1i_code_gen_complex_sampled(dst, gnss_synchro_->PRN, static_cast<int32_t>(fs_in_), 0, nullptr);
         else if (SIG == AcqSignal::GLONASS_L1_CA)
             gc_glonass_l1_ca_code_gen_complex_sampled(dst, static_cast<int32_t>(fs_in_), 0, nullptr);  // one code for every slot (FDMA)
+        else if (SIG == AcqSignal::BEIDOU_B3I)
+            gc_beidou_b3i_code_gen_complex_sampled(dst, gnss_synchro_->PRN, static_cast<int32_t>(fs_in_), 0, nullptr);
+        else if (SIG == AcqSignal::GPS_L5I)
+            gc_gps_l5i_code_gen_complex_sampled(dst, gnss_synchro_->PRN, static_cast<int32_t>(fs_in_), nullptr);
+        else if (SIG == AcqSignal::GPS_L2_M)
+            {
+                gc_gps_l2c_m_code_gen_complex_sampled(dst, gnss_synchro_->PRN, static_cast<int32_t>(fs_in_), nullptr);
+                reps = sampled_ms_ / 20;
+            }
+        else if (SIG == AcqSignal::GALILEO_E5A)
+            {
+                // galileo_e5a_pcps_acquisition.cc:238-266
+                const char* sig = acquire_iq_ ? "5X" : acquire_pilot_ ? "5Q" : "5I";
+                gc_galileo_e5_a_code_gen_complex_sampled(dst, sig, gnss_synchro_->PRN, static_cast<int32_t>(fs_in_), 0, nullptr);
+            }
         else
             {
                 // galileo_e1_pcps_ambiguous_acquisition.cc:240-284: the cboc flag is looked up per channel
@@ -255,6 +326,7 @@ private:
     unsigned int doppler_step_ = 0;
     unsigned int sampled_ms_ = 1;
     bool acquire_pilot_ = false;
+    bool acquire_iq_ = false;
     float threshold_ = 0.0f;
     int64_t fs_in_ = 0;
     std::shared_ptr<ChannelFsm> channel_fsm_;
@@ -265,6 +337,10 @@ private:
 using GpsL1CaPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GPS_L1_CA>;
 using GalileoE1PcpsAmbiguousAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GALILEO_E1>;
 using BeidouB1iPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::BEIDOU_B1I>;
+using GpsL2MPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GPS_L2_M>;
+using GpsL5iPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GPS_L5I>;
+using GalileoE5aPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GALILEO_E5A>;
+using BeidouB3iPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::BEIDOU_B3I>;
 //! the block applies the FDMA offset in set_local_code() once hip_pcps_acquisition::set_glonass_channel_map() holds the almanac
 using GlonassL1CaPcpsAcquisitionHip = PcpsAcquisitionHip<gnsscorr::AcqSignal::GLONASS_L1_CA>;
 

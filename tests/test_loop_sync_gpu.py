@@ -259,3 +259,48 @@ def test_sync_argument_checks(gctx, oracle):
     rec = loop.run(2)
     assert rec.shape == (2, 2)
     loop.close()
+
+
+def test_gps_l5_pilot_in_quadrature_on_the_device_loop(gctx, oracle):
+    """GPS L5 shape on the device loop: 10230-chip replicas at 10.23 Mcps, the pilot Q5 (NH20) in quadrature with the data
+    component I5 (NH10 x data bits).  The loop locks the pilot on the real axis, so the data symbols arrive on the imaginary part
+    of d_Prompt_Data (the block's interchange_iq, dll_pll_veml_tracking.cc:1697-1704, is the host's choice of record field)."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    i5, q5 = gnsscorr.gps_l5i_code_gen_float(24), gnsscorr.gps_l5q_code_gen_float(24)
+    nh10, nh20 = gnsscorr.secondary_code("L5I"), gnsscorr.secondary_code("L5Q")
+    fs, n_ep, N = 12.5e6, 90, 12500
+    rng = np.random.Generator(np.random.PCG64(9))
+    bits = rng.integers(0, 2, 40) * 2.0 - 1.0
+    dsym = np.array([bits[p // 10] * (1.0 if nh10[p % 10] == "0" else -1.0) for p in range(400)])
+    psym = np.array([1.0 if c == "0" else -1.0 for c in nh20])
+    # quadrature pilot: _stream sums real components on one carrier, so build the two halves and combine
+    doppler, delay = 1850.0, 4000.0
+    xi = _stream([(i5, dsym, 1.0)], fs, N * (n_ep + 3), doppler, delay, 47.0, 100, 10.23e6, carrier_hz=1176.45e6)
+    xq = _stream([(q5, psym, 1.0)], fs, N * (n_ep + 3), doppler, delay, 47.0, 101, 10.23e6, carrier_hz=1176.45e6)
+    x = ((xi + 1j * xq) / np.sqrt(2.0)).astype(np.complex64) * np.float32(np.sqrt(2.0))  # unit noise per component again
+    conf = dict(fs_in=fs, signal_carrier_freq_hz=1176.45e6, code_chip_rate_hz=10.23e6, code_period_s=0.001, carrier_lock_th=0.75,
+        code_length_chips=10230, code_samples_per_chip=1, vector_length=N, pull_in_time_s=0, veml=0, pll_filter_order=3, dll_filter_order=2,
+        enable_fll_pull_in=0, enable_fll_steady_state=0, cn0_samples=20, cn0_min=25, max_lock_fail=50, pll_bw_hz=40.0, dll_bw_hz=2.0, fll_bw_hz=35.0,
+        early_late_space_chips=0.5, very_early_late_space_chips=0.0, acq_samplestamp_samples=0, sample_counter=0, acq_delay_samples=delay,
+        acq_doppler_hz=doppler + 2.0)
+    y = dict(extend_correlation_symbols=5, track_pilot=True, symbols_per_bit=10, secondary_code=nh20, pll_bw_narrow_hz=15.0, dll_bw_narrow_hz=1.0,
+        early_late_space_narrow_chips=0.4)
+    ref = ref_run(oracle, x, q5, conf, n_ep, sync=y, data_code=i5)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 10230)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.set_sync(0, _sync(gnsscorr, y), i5)
+    loop.start(0, _conf(gnsscorr, **conf), q5)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    _compare(rec, ref, 3, abs_tol=2.2 * float(np.abs(x).max()))
+    first = int(np.argmax(rec["state"] != 2))
+    assert first == 2 * 20 - 3 and set(rec["state"][first:].tolist()) == {3, 4}
+    # the loop runs on j * pilot: the data component sits on the other axis
+    tail = slice(first + 25, n_ep)
+    got = np.sign(rec["prompt_data"][tail, 1])
+    want = dsym[(np.arange(n_ep)[tail] + 2) % dsym.size]
+    assert abs(np.sum(got * want)) == got.size
+    assert np.median(np.abs(rec["prompt_data"][tail, 1])) > 2 * np.median(np.abs(rec["prompt_data"][tail, 0]))

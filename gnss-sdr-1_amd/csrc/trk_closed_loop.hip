@@ -12,7 +12,7 @@
 // record carries what the block puts in Gnss_Synchro and in its binary dump.  The whole state machine of
 // general_work runs here: pull-in (1), wide tracking with secondary-code / preamble synchronisation (2,
 // :1601-1773), extended coherent integration (3, :1774-1826) and narrow tracking (4, :1827-1896), with the
-// data-component prompt correlator of pilot tracking (:899-910).  Not covered: high-dynamics rate smoothing.
+// data-component prompt correlator of pilot tracking (:899-910) and the high-dynamics rate smoothers (:1016-1064).
 #include "gc_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -22,6 +22,7 @@
 #include <vector>
 
 #define LOOP_MAX_CN0 64
+#define LOOP_MAX_SMOOTHER 16
 #define LOOP_PI_2 6.283185307179586
 
 // code loop filter without the last integrator (the block constructs it with include_last_integrator = false)
@@ -60,6 +61,10 @@ struct LoopChan
     float2 accu[5];         // d_VE_accu, d_E_accu, d_P_accu, d_L_accu, d_VL_accu
     float2 prompt_data;     // d_Prompt_Data
     int current_symbol, extend_count;
+    // high dynamics (:1016-1033, :1047-1064): histories of (NCO step, block length), newest last, 2 * smoother_length deep
+    double carr_hist[2 * LOOP_MAX_SMOOTHER][2], code_hist[2 * LOOP_MAX_SMOOTHER][2];
+    int carr_hist_n, code_hist_n;
+    double carrier_phase_rate_step_rad, code_phase_rate_step_chips;
     TrkChan chan;       // iq, code table, taps
     int n_taps;
     int state;          // 0 standby, 1 pull-in, 2 tracking
@@ -246,6 +251,8 @@ static __device__ void loop_start(LoopChan& s)
     s.extend_count = 0;
     s.hist_count = 0;
     for (int i = 0; i < 6; i++) s.hist[i] = 0u;
+    s.carrier_phase_rate_step_rad = s.code_phase_rate_step_chips = 0.0;
+    s.carr_hist_n = s.code_hist_n = 0;
 }
 
 // cn0_and_tracking_lock_status (:839-878); false = loss of lock
@@ -302,6 +309,8 @@ static __device__ __forceinline__ void loop_clear_tracking_vars(LoopChan& s)
     s.current_symbol = 0;
     s.hist_count = 0;
     for (int i = 0; i < 6; i++) s.hist[i] = 0u;
+    s.carrier_phase_rate_step_rad = s.code_phase_rate_step_chips = 0.0;
+    s.carr_hist_n = s.code_hist_n = 0;
 }
 
 // run_dll_pll (:914-973) on the accumulators
@@ -342,19 +351,52 @@ static __device__ __forceinline__ void loop_run_dll_pll(LoopChan& s, bool veml)
     s.code_freq_chips = (1.0 + (s.carrier_doppler_hz / c.signal_carrier_freq_hz)) * c.code_chip_rate_hz - s.code_error_filt_chips;
 }
 
-// update_tracking_vars (:998-1070), no high-dynamics terms
+// the rate smoother of both NCOs (:1016-1033, :1047-1064): once 2 * smoother_length (value, samples) pairs are held, the
+// rate is (mean of the newer half - mean of the older half) / samples of the newer half
+static __device__ __forceinline__ double loop_smoothed_rate(double (*hist)[2], int& count, int sl, double value, double samples, double current)
+{
+    const int cap = 2 * sl;
+    if (count == cap)
+        {
+            for (int k = 1; k < cap; k++)
+                {
+                    hist[k - 1][0] = hist[k][0];
+                    hist[k - 1][1] = hist[k][1];
+                }
+            count--;
+        }
+    hist[count][0] = value;
+    hist[count][1] = samples;
+    count++;
+    if (count < cap) return current;
+    double cp1 = 0.0, cp2 = 0.0, ns = 0.0;
+    for (int k = 0; k < sl; k++)
+        {
+            cp1 += hist[k][0];
+            cp2 += hist[cap - k - 1][0];
+            ns += hist[cap - k - 1][1];
+        }
+    cp1 /= (double)sl;
+    cp2 /= (double)sl;
+    return (cp2 - cp1) / ns;
+}
+
+// update_tracking_vars (:998-1070)
 static __device__ __forceinline__ void loop_update_tracking_vars(LoopChan& s)
 {
     const gc_loop_conf& c = s.conf;
+    const int sl = (int)c.high_dyn_smoother_length;
     const double T_prn_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
     const double K_blk_samples = T_prn_samples + s.rem_code_phase_samples;
     s.current_prn_length_samples = (int)floor(K_blk_samples);
     s.carrier_phase_step_rad = LOOP_PI_2 * s.carrier_doppler_hz / c.fs_in;
     const double n = (double)s.current_prn_length_samples;
-    s.rem_carr_phase_rad += (float)(s.carrier_phase_step_rad * n);
+    if (sl > 0) s.carrier_phase_rate_step_rad = loop_smoothed_rate(s.carr_hist, s.carr_hist_n, sl, s.carrier_phase_step_rad, n, s.carrier_phase_rate_step_rad);
+    s.rem_carr_phase_rad += (float)(s.carrier_phase_step_rad * n + 0.5 * s.carrier_phase_rate_step_rad * n * n);
     s.rem_carr_phase_rad = fmodf(s.rem_carr_phase_rad, (float)LOOP_PI_2);
-    s.acc_carrier_phase_rad -= s.carrier_phase_step_rad * n;
+    s.acc_carrier_phase_rad -= (s.carrier_phase_step_rad * n + 0.5 * s.carrier_phase_rate_step_rad * n * n);
     s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+    if (sl > 0) s.code_phase_rate_step_chips = loop_smoothed_rate(s.code_hist, s.code_hist_n, sl, s.code_phase_step_chips, n, s.code_phase_rate_step_chips);
     s.rem_code_phase_samples = K_blk_samples - n;
     s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
 }
@@ -565,7 +607,8 @@ static __device__ __forceinline__ void loop_after_correlation(LoopChan& s, const
 
 // THREADS per channel: 1024 when there are few channels (one workgroup per CU), 256 when there are many
 // DATA: pilot tracking, every channel carries the data component's replica (chan.code2)
-template <int NTAPS, int THREADS, int FMT, bool DATA>
+// HD:   Dll_Pll_Conf::high_dyn -- the high-dynamics resampler and rotator (carrier and code rate terms)
+template <int NTAPS, int THREADS, int FMT, bool DATA, bool HD = false>
 __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
     gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats, const unsigned long long* __restrict__ limits)
 {
@@ -626,11 +669,12 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
                             s_p.phase0_im = -sinf(rem_carr);
                             s_p.phase_inc_re = cosf(pstep);
                             s_p.phase_inc_im = -sinf(pstep);
-                            s_p.phase_rate_re = 1.0f;
-                            s_p.phase_rate_im = 0.0f;
+                            const float prate = HD ? (float)s.carrier_phase_rate_step_rad : 0.0f;
+                            s_p.phase_rate_re = cosf(prate);
+                            s_p.phase_rate_im = -sinf(prate);
                             s_p.rem_code_phase_chips = (float)s.rem_code_phase_chips * spc;
                             s_p.code_phase_step_chips = (float)s.code_phase_step_chips * spc;
-                            s_p.code_phase_rate_step_chips = 0.0f;
+                            s_p.code_phase_rate_step_chips = HD ? (float)s.code_phase_rate_step_chips * spc : 0.0f;
                             s_p.n_samples = (int)c.vector_length;
                         }
                     else
@@ -647,7 +691,7 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
             __syncthreads();
             if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
 
-            const float2 r = trk_epoch<NTAPS, false, false, FMT, false, false, THREADS, DATA>(s.chan, s_p, 0, 1, lds_table_floats, lds);
+            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA>(s.chan, s_p, 0, 1, lds_table_floats, lds);
             if (tid < NTAPS + (DATA ? 1 : 0)) s_corr[tid] = r;
             __syncthreads();
 
@@ -681,6 +725,7 @@ struct gc_trk_loop
     std::vector<LoopSync> sync;               // per channel (gc_trk_loop_set_sync); extend_symbols == 0: none installed
     std::vector<char> has_data_code;
     int pilot = -1;                           // pilot mode of the started channels (-1: none started yet)
+    int high_dyn = 0;                         // high-dynamics mode of the started channels
     gc_loop_record* d_recs = nullptr;
     size_t recs_cap = 0;
     int forced_threads = 0;  // $GNSSCORR_LOOP_THREADS (256 / 512 / 1024): tuning knob
@@ -888,6 +933,7 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
     GC_REQUIRE(conf->vector_length > 0 && conf->fs_in > 0 && conf->code_chip_rate_hz > 0, "gc_trk_loop_start: bad signal description");
     GC_REQUIRE((uint32_t)code_length == conf->code_length_chips * conf->code_samples_per_chip,
         "gc_trk_loop_start: code_length %d != code_length_chips * code_samples_per_chip", code_length);
+    GC_REQUIRE(conf->high_dyn_smoother_length <= LOOP_MAX_SMOOTHER, "gc_trk_loop_start: high_dyn_smoother_length must be <= %d", LOOP_MAX_SMOOTHER);
     const int n_taps = conf->veml ? 5 : 3;
     if (l->n_taps == 0) l->n_taps = n_taps;
     GC_REQUIRE(l->n_taps == n_taps, "gc_trk_loop_start: all channels of one loop engine use the same tap count (%d)", l->n_taps);
@@ -910,8 +956,15 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
         for (int i = 0; i < l->n_channels; i++) others_started |= (i != ch && l->started[i]);
         if (!others_started) l->pilot = -1;
     }
-    if (l->pilot < 0) l->pilot = y.track_pilot;
+    const int hd = conf->high_dyn_smoother_length > 0 ? 1 : 0;
+    if (l->pilot < 0)
+        {
+            l->pilot = y.track_pilot;
+            l->high_dyn = hd;
+        }
     GC_REQUIRE(l->pilot == y.track_pilot, "gc_trk_loop_start: all channels of one loop engine share the pilot mode (track_pilot = %d)", l->pilot);
+    GC_REQUIRE(l->high_dyn == hd, "gc_trk_loop_start: all channels of one loop engine share the high_dyn mode (%d)", l->high_dyn);
+    GC_REQUIRE(!(hd && y.track_pilot), "gc_trk_loop_start: high_dyn together with track_pilot is not available in the device loop");
     hipStream_t st = l->ctx->stream;
     GC_HIP(hipStreamSynchronize(st));
     GC_HIP(hipMemcpy(l->d_codes + (size_t)ch * l->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
@@ -1030,7 +1083,28 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
             else LAUNCH_LOOP(NT, TH, GC_IQ_F32);                          \
         }                                                                 \
     while (0)
-    if (l->n_taps == 5)
+    if (l->high_dyn)
+        {
+            // high-dynamics kernels: 256 threads per channel (the per-sample exact rotator keeps a workgroup busy)
+#define LAUNCH_LOOP_HD(NT, FM)                                                                                                                   \
+    hipLaunchKernelGGL((trk_closed_loop_kernel<NT, 256, FM, false, true>), dim3(l->n_channels), dim3(256), lds_bytes_hd, st, l->d_chans, dev_records, \
+        n_epochs, lds_table_floats, limits)
+            const size_t lds_bytes_hd = (size_t)(trk_hdr_floats(256) + lds_table_floats) * sizeof(float);
+            if (l->n_taps == 5)
+                {
+                    if (l->iq_format == GC_IQ_I16) LAUNCH_LOOP_HD(5, GC_IQ_I16);
+                    else if (l->iq_format == GC_IQ_I8) LAUNCH_LOOP_HD(5, GC_IQ_I8);
+                    else LAUNCH_LOOP_HD(5, GC_IQ_F32);
+                }
+            else
+                {
+                    if (l->iq_format == GC_IQ_I16) LAUNCH_LOOP_HD(3, GC_IQ_I16);
+                    else if (l->iq_format == GC_IQ_I8) LAUNCH_LOOP_HD(3, GC_IQ_I8);
+                    else LAUNCH_LOOP_HD(3, GC_IQ_F32);
+                }
+#undef LAUNCH_LOOP_HD
+        }
+    else if (l->n_taps == 5)
         {
             if (threads == 1024) LAUNCH_LOOP_FMT(5, 1024);
             else if (threads == 512) LAUNCH_LOOP_FMT(5, 512);

@@ -103,7 +103,7 @@ class LoopConf(C.Structure):
         ("enable_fll_pull_in", C.c_int32), ("enable_fll_steady_state", C.c_int32), ("cn0_samples", C.c_int32),
         ("cn0_min", C.c_int32), ("max_lock_fail", C.c_int32), ("pll_bw_hz", C.c_float), ("dll_bw_hz", C.c_float),
         ("fll_bw_hz", C.c_float), ("early_late_space_chips", C.c_float), ("very_early_late_space_chips", C.c_float),
-        ("reserved", C.c_uint32),
+        ("high_dyn_smoother_length", C.c_uint32),
     ]
 
 

@@ -285,7 +285,9 @@ typedef struct
     int32_t cn0_samples, cn0_min, max_lock_fail;
     float pll_bw_hz, dll_bw_hz, fll_bw_hz;
     float early_late_space_chips, very_early_late_space_chips;
-    uint32_t reserved;
+    uint32_t high_dyn_smoother_length; /* 0: Dll_Pll_Conf::high_dyn false; n > 0: high_dyn with smoother_length n (<= 16): the
+                                        * high-dynamics resampler / rotator kernels and the carrier / code rate smoothers of
+                                        * update_tracking_vars (:1016-1033, :1047-1064); not combined with track_pilot here */
 } gc_loop_conf;
 
 /* One code period of one channel: the correlator outputs plus what the block writes to Gnss_Synchro

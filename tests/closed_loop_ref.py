@@ -139,6 +139,19 @@ def run(oracle, x, code, conf, n_epochs, sync=None, data_code=None):
         perr=0.0, cerr=0.0, hist=[], current_symbol=0, ext_count=0, pull_in=True, P_old=np.complex64(0))
     accu = np.zeros(5, np.complex64)  # VE E P L VL
     out = []
+    # high dynamics (:1016-1033, :1047-1064)
+    sl = int(conf.get("high_dyn_smoother_length", 0))
+    hd = dict(carr=[], code=[], carr_rate=0.0, code_rate=0.0)
+
+    def smoothed(hist, value, samples, current):
+        hist.append((value, samples))
+        del hist[:-2 * sl]
+        if len(hist) < 2 * sl:
+            return current
+        cp1 = sum(h[0] for h in hist[:sl]) / sl
+        newer = [hist[2 * sl - k - 1] for k in range(sl)]
+        cp2 = sum(h[0] for h in newer) / sl
+        return (cp2 - cp1) / sum(h[1] for h in newer)
 
     def lock_status(coh_time):
         if len(st["prompt_buffer"]) < conf["cn0_samples"]:
@@ -201,10 +214,15 @@ def run(oracle, x, code, conf, n_epochs, sync=None, data_code=None):
         cur = int(np.floor(K))
         st["cur"] = cur
         step = PI_2 * doppler / fs
-        rem_carr = f32(rem_carr + f32(step * cur))
+        if sl:
+            hd["carr_rate"] = smoothed(hd["carr"], step, float(cur), hd["carr_rate"])
+        adv = step * cur + 0.5 * hd["carr_rate"] * float(cur) * float(cur)
+        rem_carr = f32(rem_carr + f32(adv))
         rem_carr = f32(np.fmod(rem_carr, f32(PI_2)))
-        acc_phase -= step * cur
+        acc_phase -= adv
         code_step = code_freq / fs
+        if sl:
+            hd["code_rate"] = smoothed(hd["code"], code_step, float(cur), hd["code_rate"])
         rem_code_samples = K - cur
         rem_code_chips = code_freq * rem_code_samples / fs
 
@@ -229,6 +247,8 @@ def run(oracle, x, code, conf, n_epochs, sync=None, data_code=None):
         if st["pull_in"] and conf["pull_in_time_s"] < (sample_counter - acq_stamp) // int(fs):
             st["pull_in"] = False
         args = (f32(rem_carr), f32(step), f32(f32(rem_code_chips) * f32(spc)), f32(f32(code_step) * f32(spc)), N)
+        if sl:
+            args = args + (f32(hd["carr_rate"]), f32(f32(hd["code_rate"]) * f32(spc)), True)
         corr = oracle.multicorrelator(x[pos:], code, shifts, *args)
         pdata = oracle.multicorrelator(x[pos:], data_code, shifts[len(shifts) // 2:len(shifts) // 2 + 1], *args)[0] if pilot else corr[len(shifts) // 2]
         P = corr[len(shifts) // 2]
@@ -241,6 +261,7 @@ def run(oracle, x, code, conf, n_epochs, sync=None, data_code=None):
             if not lock_status(conf["code_period_s"]):
                 st["state"] = 0
                 log_accu = accu.copy()
+                hd.update(carr=[], code=[], carr_rate=0.0, code_rate=0.0)
             else:
                 run_dll_pll()
                 update_tracking_vars()

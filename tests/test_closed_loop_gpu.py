@@ -242,3 +242,51 @@ def test_closed_loop_workgroup_sizes_agree(gctx, oracle):
         assert np.array_equal(r["current_prn_length_samples"], base["current_prn_length_samples"])
         assert np.max(np.abs(r["corr"] - base["corr"])) <= 2e-5 * np.max(np.abs(base["corr"]))
         assert np.max(np.abs(r["carrier_doppler_hz"] - base["carrier_doppler_hz"])) < 0.02
+
+
+def test_closed_loop_high_dynamics(gctx, oracle):
+    """Dll_Pll_Conf::high_dyn on the device loop: the high-dynamics resampler / rotator kernels plus the carrier and code rate
+    smoothers of update_tracking_vars (dll_pll_veml_tracking.cc:1016-1033, :1047-1064), on a signal whose Doppler ramps at
+    400 Hz/s, against the CPU restatement; the smoothed carrier rate converges to the ramp."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    fs, n_ep, ramp = 4e6, 220, 400.0
+    code = oracle.gps_l1_ca_code(11).astype(np.float32)
+    rng = np.random.Generator(np.random.PCG64(55))
+    n = 4000 * (n_ep + 3)
+    t = np.arange(n) / fs
+    f0 = 900.0
+    phase = 2 * np.pi * (f0 * t + 0.5 * ramp * t * t)
+    tau = (1023.0 - 321.0 * 1.023e6 / fs) + 1.023e6 * (t + (f0 * t + 0.5 * ramp * t * t) / 1575.42e6)
+    chip = np.floor(tau).astype(np.int64) % 1023
+    amp = np.sqrt(10 ** (50.0 / 10) / fs)
+    x = (amp * code[chip] * np.exp(1j * (phase + 0.3)) + (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.sqrt(0.5)).astype(np.complex64)
+    conf = dict(GPS, acq_delay_samples=321.0, acq_doppler_hz=f0 + 3.0, acq_samplestamp_samples=0, sample_counter=0, high_dyn_smoother_length=8,
+        pull_in_time_s=0)
+    ref = ref_run(oracle, x, code, conf, n_ep)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    assert len(ref) == n_ep and np.all(rec["valid"] == 1)
+    one = 2.2 * float(np.abs(x).max())
+    for k in range(n_ep):
+        r, g = ref[k], rec[k]
+        assert int(g["sample_counter"]) == r["sample_counter"], k
+        gp = g["corr"][2] + 1j * g["corr"][3]
+        assert abs(gp - r["corr"][1]) <= max(2e-3 * abs(r["corr"][1]), one), k
+        assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.3, k
+    # the loop follows the ramp: Doppler at the end is f0 + ramp * t
+    t_end = float(rec["sample_counter"][-1]) / fs
+    assert abs(float(rec["carrier_doppler_hz"][-1]) - (f0 + ramp * t_end)) < 8.0
+    # one engine, one mode
+    loop = gnsscorr.TrackingLoop(gctx, 2, 1023)
+    for ch in range(2):
+        loop.set_input_dev(ch, d.data_ptr(), x.size)
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    with pytest.raises(gnsscorr.GnsscorrError, match="high_dyn mode"):
+        loop.start(1, _conf(gnsscorr, **dict(conf, high_dyn_smoother_length=0)), code)
+    loop.close()

@@ -697,6 +697,16 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_cols_kernel(AcqFftPlan plan, 
             MaxPair best = {-1.0f, 0xffffffffu};
             if (active)
                 {
+                    // non-coherent accumulation: all previous grid values are fetched before the first store (the compiler
+                    // cannot prove that g[idx(k)] and g[idx(k')] differ, so a load after a store would wait for it: N1 serial
+                    // round trips made the accumulating launches 2.5x slower than the first dwell's)
+                    float prev[N1];
+#pragma unroll
+                    for (int k = 0; k < N1; k++)
+                        {
+                            const int idx = n2 + N2 * k - mag.offset;
+                            prev[k] = (mag.accumulate && idx >= 0 && idx < mag.eff) ? g[idx] : 0.0f;
+                        }
 #pragma unroll
                     for (int k = 0; k < N1; k++)
                         {
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(ACQ_THREADS) void acq_cols_kernel(AcqFftPlan plan, 
                                     if (mag.accumulate)
                                         {
                                             if (tmp) tmp[idx] = p;
-                                            val = g[idx] + p;
+                                            val = prev[k] + p;
                                         }
                                     g[idx] = val;
                                     MaxPair c = {val, (unsigned)idx};
@@ -955,23 +965,39 @@ __global__ __launch_bounds__(ACQ_FINAL_THREADS) void acq_final_kernel(AcqFinalAr
             // memcpy(d_tmp_buffer, row, d_fft_size) copies d_fft_size BYTES = N/4 floats (:647)
             const int n_copied = N / 4;
             MaxPair best_bug = {-1.0f, 0xffffffffu}, best_full = {-1.0f, 0xffffffffu};
-            for (int i = tid; i < N; i += ACQ_FINAL_THREADS)
+            // four elements per thread and step: the eight loads are issued before the first one is used (one dependent
+            // load per element made this loop the whole 24 us of the kernel)
+            constexpr int U = 4;
+            for (int i0 = tid; i0 < N; i0 += U * ACQ_FINAL_THREADS)
                 {
-                    int d = i - e1;
-                    if (d < 0) d += N;
-                    const bool excluded = d < len;
-                    const float g = grow[i];
-                    float vb = (i < n_copied) ? g : tmp[i];
-                    float vf = g;
-                    if (excluded)
+                    float g[U], t[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++)
                         {
-                            vb = 0.0f;
-                            vf = 0.0f;
+                            const int i = i0 + u * ACQ_FINAL_THREADS;
+                            g[u] = i < N ? grow[i] : 0.0f;
+                            t[u] = (i < N && i >= n_copied) ? tmp[i] : 0.0f;
                         }
-                    tmp[i] = vb;  // the scratch keeps these contents for the next call, like d_tmp_buffer
-                    MaxPair cb = {vb, (unsigned)i}, cf = {vf, (unsigned)i};
-                    best_bug = max_pair(best_bug, cb);
-                    best_full = max_pair(best_full, cf);
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                        {
+                            const int i = i0 + u * ACQ_FINAL_THREADS;
+                            if (i >= N) continue;
+                            int d = i - e1;
+                            if (d < 0) d += N;
+                            const bool excluded = d < len;
+                            float vb = (i < n_copied) ? g[u] : t[u];
+                            float vf = g[u];
+                            if (excluded)
+                                {
+                                    vb = 0.0f;
+                                    vf = 0.0f;
+                                }
+                            tmp[i] = vb;  // the scratch keeps these contents for the next call, like d_tmp_buffer
+                            MaxPair cb = {vb, (unsigned)i}, cf = {vf, (unsigned)i};
+                            best_bug = max_pair(best_bug, cb);
+                            best_full = max_pair(best_full, cf);
+                        }
                 }
             for (int pass = 0; pass < 2; pass++)
                 {

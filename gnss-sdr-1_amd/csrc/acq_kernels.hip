@@ -781,6 +781,40 @@ __global__ void acq_permute_kernel(const float2* __restrict__ in, const float2* 
     out[(size_t)arr * out_stride + o] = v;
 }
 
+// The same gather through LDS: the sources of 64 consecutive b and all a, src = a + N1*b, are ONE contiguous range of
+// 64*N1 elements, and out[a*N2 + b0 .. b0+63] is contiguous for each a: both sides coalesced (the plain kernel reads with a
+// stride of N1 elements: 14 us per dwell for 41 bins of N = 25000, 4 us this way).
+#define ACQ_PERM_TB 64
+__global__ __launch_bounds__(256) void acq_permute_tiled_kernel(const float2* __restrict__ in, const float2* __restrict__ mul,
+    float2* __restrict__ out, int N, int N1, int N2, int n_valid, size_t in_stride, size_t mul_stride, size_t out_stride)
+{
+    extern __shared__ float2 tile[];  // [ACQ_PERM_TB * N1]
+    const int arr = blockIdx.y;
+    const int b0 = blockIdx.x * ACQ_PERM_TB;
+    const int nb = min(ACQ_PERM_TB, N2 - b0);
+    const int base = N1 * b0, count = N1 * nb;
+    for (int i = threadIdx.x; i < count; i += 256)
+        {
+            const int src = base + i;
+            float2 v = make_float2(0.f, 0.f);
+            if (src < n_valid)
+                {
+                    v = in[(size_t)arr * in_stride + src];
+                    if (mul)
+                        {
+                            // volk_32fc_x2_multiply_32fc(in, wipeoff) (pcps_acquisition.cc:717)
+                            const float2 w = mul[(size_t)arr * mul_stride + src];
+                            v = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+                        }
+                }
+            tile[i] = v;
+        }
+    __syncthreads();
+    const int j = threadIdx.x & (ACQ_PERM_TB - 1);
+    for (int a = threadIdx.x / ACQ_PERM_TB; a < N1; a += 256 / ACQ_PERM_TB)
+        if (j < nb) out[(size_t)arr * out_stride + (size_t)a * N2 + b0 + j] = tile[a + N1 * j];
+}
+
 // ---- Doppler wipe-off table (pcps_acquisition::update_local_carrier, :296-310) ----
 // volk_gnsssdr_s32f_sincos_32fc_generic: _phase += phase_inc in float32, out = (cosf, sinf)
 __global__ void acq_wipeoff_phase_kernel(const float* __restrict__ phase_inc, float* __restrict__ phase, int n_bins, int N)
@@ -1146,6 +1180,18 @@ bool acq_plan_make(AcqFftPlan* plan, int N, size_t lds_limit_bytes)
 hipError_t acq_launch_permute(hipStream_t st, const float2* in, const float2* mul, float2* out,
     const AcqFftPlan& plan, int n_valid, int n_arrays, size_t in_stride, size_t mul_stride, size_t out_stride)
 {
+    static const bool plain = [] {
+        const char* e = std::getenv("GNSSCORR_ACQ_PERMUTE");
+        return e && std::strcmp(e, "plain") == 0;
+    }();
+    const size_t lds = sizeof(float2) * ACQ_PERM_TB * (size_t)plan.N1;
+    if (!plain && lds <= 48 * 1024)
+        {
+            dim3 grid((plan.N2 + ACQ_PERM_TB - 1) / ACQ_PERM_TB, n_arrays);
+            hipLaunchKernelGGL(acq_permute_tiled_kernel, grid, dim3(256), lds, st, in, mul, out, plan.N, plan.N1, plan.N2, n_valid, in_stride, mul_stride,
+                out_stride);
+            return hipGetLastError();
+        }
     dim3 grid((plan.N + 255) / 256, n_arrays);
     hipLaunchKernelGGL(acq_permute_kernel, grid, dim3(256), 0, st, in, mul, out, plan.N, plan.N1, plan.N2, n_valid,
         in_stride, mul_stride, out_stride);

@@ -155,13 +155,20 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
         }
     const size_t N = a->fft_size;
     a->n_blocks = acq_cols_blocks(a->plan);
-    // scratch Q: keep a batch of satellites within ~96 MB so that it lives in the Infinity Cache
+    // scratch Q: a batch of satellites stays within ~140 MB (it lives in the 256 MB Infinity Cache between the two passes), and the
+    // batches are equal: a launch's workgroups run in rounds of (CUs x workgroups per CU), so the time of a pass steps with the
+    // round count -- 11 + 11 + 10 satellites x 41 bins cost 3 + 3 + 2 rounds of the row pass, 16 + 16 cost 4 + 4 with fewer, larger
+    // launches (measured 0.53 -> 0.50 ms per search)
     size_t per_sat = (size_t)a->n_bins_alloc * N * sizeof(float2);
-    size_t q_budget = (size_t)96 << 20;
+    size_t q_budget = (size_t)140 << 20;
     if (const char* e = std::getenv("GNSSCORR_ACQ_Q_MB")) q_budget = (size_t)std::max(1, std::atoi(e)) << 20;
     a->sats_per_batch = (int)(q_budget / per_sat);
     if (a->sats_per_batch < 1) a->sats_per_batch = 1;
     if (a->sats_per_batch > n_sats) a->sats_per_batch = n_sats;
+    {
+        const int n_batches = (n_sats + a->sats_per_batch - 1) / a->sats_per_batch;
+        a->sats_per_batch = (n_sats + n_batches - 1) / n_batches;
+    }
     size_t q_cells = (size_t)a->sats_per_batch * a->n_bins_alloc;
 
     ACQ_TRY(hipMalloc(&a->d_wN, N * sizeof(float2)));

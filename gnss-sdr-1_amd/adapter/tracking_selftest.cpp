@@ -6,6 +6,7 @@
 // with known Doppler / code phase; the loop must pull in and stay locked, and its Doppler / C/N0 estimates
 // must converge to the truth.  Usage: tracking_selftest (needs a GPU).
 #include "dll_pll_tracking_adapters.h"
+#include "hip_glonass_ca_dll_pll_tracking.h"
 #include "pcps_acquisition_adapters.h"
 #include <cmath>
 #include <cstdio>
@@ -588,6 +589,76 @@ static void test_beidou_b3i_and_gps_l2c()
     }
 }
 
+static void test_glonass_fdma_tracking()
+{
+    // GLONASS L1 C/A, slot 22 = frequency channel -3: the signal sits 3 x 562.5 kHz below the band centre; the block's carrier NCO
+    // carries that offset, its Doppler bookkeeping does not (glonass_l1_ca_dll_pll_tracking_cc.cc:173-214, :604-639)
+    const double fs = 6.625e6, fd = 2100.0, cn0 = 46.0, delay_samples = 1343.0;
+    const double f_channel = -3 * 562500.0;
+    std::vector<float> code(511);
+    gc_glonass_l1_ca_code_gen_float(code.data(), 0);
+    // the code Doppler follows the slot's own carrier (1602 MHz - 1.6875 MHz)
+    auto x = synth(code, 0.511e6, 1.602e9 + f_channel, fs, 6625 * 900, fd, 511.0 - delay_samples * 0.511e6 / fs, cn0, 51);
+    // shift the whole signal (not the noise statistics) down to the channel's centre
+    {
+        std::mt19937 gen(52);
+        for (size_t i = 0; i < x.size(); i++)
+            {
+                const double ph = 2.0 * M_PI * std::fmod(f_channel * static_cast<double>(i) / fs, 1.0);
+                x[i] *= gr_complex(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+            }
+    }
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "6625000");
+    config.set_property("Tracking_1G.pll_bw_hz", "40.0");
+    config.set_property("Tracking_1G.dll_bw_hz", "3.0");
+    Gnss_Synchro syn;
+    syn.System = 'R';
+    syn.Signal[0] = '1';
+    syn.Signal[1] = 'G';
+    syn.PRN = 22;
+    syn.Acq_delay_samples = delay_samples;
+    syn.Acq_doppler_hz = fd + 40.0;
+    syn.Acq_samplestamp_samples = 0;
+    GlonassL1CaDllPllTrackingHip trk(&config, "Tracking_1G", 1, 1);
+    EXPECT(trk.implementation() == "GLONASS_L1_CA_DLL_PLL_Tracking_HIP" && trk.vector_length() == 6625, "GLONASS adapter: %u samples", trk.vector_length());
+    trk.set_gnss_synchro(&syn);
+    trk.start_tracking();
+    auto blk = trk.block();
+    size_t pos = 0;
+    int epochs = 0, averaged = 0;
+    double mean_doppler = 0.0, mean_nco = 0.0;
+    Gnss_Synchro out;
+    while (pos + blk->required_input_items() <= x.size() && blk->tracking_enabled())
+        {
+            int produced = 0;
+            pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+            if (epochs >= 400)
+                {
+                    // the block's frequency estimate is the running sum of the loop filter output: noisy period by period
+                    // (some +-15 Hz at 40 Hz of bandwidth), unbiased on average
+                    mean_doppler += blk->carrier_doppler_hz();
+                    mean_nco += blk->carrier_frequency_hz();
+                    averaged++;
+                }
+            if (std::getenv("GNSSCORR_SELFTEST_VERBOSE") && epochs % 50 == 0)
+                std::printf("  %d: Doppler %.3f, P = (%.0f, %.0f), counter %llu\n", epochs, blk->carrier_doppler_hz(), blk->correlator_outs()[1].real(),
+                    blk->correlator_outs()[1].imag(), (unsigned long long)blk->sample_counter());
+            epochs++;
+        }
+    EXPECT(blk->last_status() == GC_OK, "GLONASS: engine status %d (%s)", blk->last_status(), gc_last_error());
+    EXPECT(blk->tracking_enabled() && blk->events().empty(), "GLONASS: lost lock after %d periods", epochs);
+    mean_doppler /= std::max(1, averaged);
+    mean_nco /= std::max(1, averaged);
+    EXPECT(averaged > 400 && std::fabs(mean_doppler - fd) < 3.0, "GLONASS: mean Doppler %.2f Hz over %d periods, truth %.2f", mean_doppler, averaged, fd);
+    EXPECT(std::fabs(mean_nco - (fd + f_channel)) < 3.0, "GLONASS: mean NCO frequency %.2f Hz", mean_nco);
+    EXPECT(std::fabs(blk->cn0_db_hz() - cn0) < 3.0 && blk->carrier_lock_test() > 0.85, "GLONASS: C/N0 %.1f, lock test %.3f", blk->cn0_db_hz(), blk->carrier_lock_test());
+    const auto& c = blk->correlator_outs();
+    EXPECT(std::abs(c[1]) > std::abs(c[0]) && std::abs(c[1]) > std::abs(c[2]), "GLONASS: prompt is not the largest tap");
+    std::printf("GLONASS L1 C/A (slot 22, channel -3): %d periods, mean Doppler %.2f Hz (truth %.2f), mean NCO %.2f Hz, C/N0 %.1f dB-Hz, lock test %.3f\n", epochs,
+        mean_doppler, fd, mean_nco, blk->cn0_db_hz(), blk->carrier_lock_test());
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -633,6 +704,7 @@ int main()
     test_gps_l5_pilot();
     test_galileo_e5a_pilot();
     test_beidou_b3i_and_gps_l2c();
+    test_glonass_fdma_tracking();
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

@@ -723,7 +723,7 @@ struct gc_trk_loop
     float* d_codes = nullptr;
     float* d_data_codes = nullptr;            // pilot tracking: data-component replicas, allocated on first use
     std::vector<LoopSync> sync;               // per channel (gc_trk_loop_set_sync); extend_symbols == 0: none installed
-    std::vector<char> has_data_code;
+    std::vector<int> data_code_len;           // samples of the data replica uploaded for the channel (0: none)
     int pilot = -1;                           // pilot mode of the started channels (-1: none started yet)
     int high_dyn = 0;                         // high-dynamics mode of the started channels
     gc_loop_record* d_recs = nullptr;
@@ -772,7 +772,7 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
     (void)hipMemset(l->d_chans, 0, sizeof(LoopChan) * n_channels);
     l->started.assign(n_channels, 0);
     l->sync.assign(n_channels, LoopSync());
-    l->has_data_code.assign(n_channels, 0);
+    l->data_code_len.assign(n_channels, 0);
     l->iq.assign(n_channels, nullptr);
     l->n_iq.assign(n_channels, 0);
     l->streams.assign(n_channels, nullptr);
@@ -872,7 +872,7 @@ gc_status gc_trk_loop_set_sync(gc_trk_loop* l, int ch, const gc_loop_sync_conf* 
         {
             std::lock_guard<std::mutex> lk(l->ctx->mtx);
             l->sync[ch] = LoopSync();
-            l->has_data_code[ch] = 0;
+            l->data_code_len[ch] = 0;
             return GC_OK;
         }
     GC_REQUIRE(sync->extend_correlation_symbols >= 1, "gc_trk_loop_set_sync: extend_correlation_symbols must be >= 1");
@@ -915,9 +915,7 @@ gc_status gc_trk_loop_set_sync(gc_trk_loop* l, int ch, const gc_loop_sync_conf* 
             if (!l->d_data_codes) GC_HIP(hipMalloc(&l->d_data_codes, sizeof(float) * (size_t)l->n_channels * l->max_code_len));
             GC_HIP(hipStreamSynchronize(l->ctx->stream));
             GC_HIP(hipMemcpy(l->d_data_codes + (size_t)ch * l->max_code_len, data_code, sizeof(float) * data_code_length, hipMemcpyHostToDevice));
-            l->has_data_code[ch] = 1;
-            // the table that follows code_length floats of replica must be the same length: checked at start
-            y.track_pilot = data_code_length;  // carried to gc_trk_loop_start, normalised to 1 there
+            l->data_code_len[ch] = data_code_length;  // must equal the tracking replica's length: checked at start
         }
     l->sync[ch] = y;
     return GC_OK;
@@ -947,10 +945,8 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
             y.symbols_per_bit = 2;
         }
     if (y.track_pilot)
-        {
-            GC_REQUIRE(y.track_pilot == code_length, "gc_trk_loop_start: the data replica has %d samples, the tracking replica %d", y.track_pilot, code_length);
-            y.track_pilot = 1;
-        }
+        GC_REQUIRE(l->data_code_len[ch] == code_length, "gc_trk_loop_start: the data replica has %d samples, the tracking replica %d", l->data_code_len[ch],
+            code_length);
     {
         bool others_started = false;
         for (int i = 0; i < l->n_channels; i++) others_started |= (i != ch && l->started[i]);

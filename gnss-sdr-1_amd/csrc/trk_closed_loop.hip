@@ -22,6 +22,10 @@
 #include <vector>
 
 #define LOOP_MAX_CN0 64
+#ifndef LOOP_PF
+#define LOOP_PF 2  // 16-byte loads in flight per lane; 4 was measured slower (0.72 vs 0.68 ms for 256 channels x 64 periods): a lone
+                   // workgroup per CU is bound by instruction issue at two waves per SIMD, not by loads in flight
+#endif
 #define LOOP_MAX_SMOOTHER 16
 #define LOOP_PI_2 6.283185307179586
 
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
             __syncthreads();
             if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
 
-            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA>(s.chan, s_p, 0, 1, lds_table_floats, lds);
+            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA, LOOP_PF>(s.chan, s_p, 0, 1, lds_table_floats, lds);
             if (tid < NTAPS + (DATA ? 1 : 0)) s_corr[tid] = r;
             __syncthreads();
 

@@ -162,7 +162,9 @@ static __device__ __forceinline__ int floor_to_int(float x)
 //             component's replica, slaved to the pilot prompt tap (same shift pointer, same NCO scalars, hence
 //             the same chip index): table2 holds the data replica laid out like `table`; its sum goes to
 //             accr[NTAPS] / acci[NTAPS] (plain float mode only)
-template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false>
+//   PF      : full chunks kept in flight per lane ahead of the one being processed (2 everywhere: deeper queues were measured
+//             no faster in the batched kernel and slower in the closed-loop kernel)
+template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF>
 static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
     int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
@@ -380,30 +382,65 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
             // prefetches past the end re-read the last full chunk (in bounds, value unused): no branch
             // in the loop body, so the compiler can wait with vmcnt(1) and keep one load in flight
             const int clast = cf1 - 1;
-            f32x4 x0 = load_full(c);
-            f32x4 x1 = load_full(min(c + 1, clast));
-            while (c < cf1)
+            if constexpr (PF == 2)
                 {
-                    if ((c - c0) % TRK_RESYNC == 0) resync(c);
-                    const int gend = min(cf1, c0 + ((c - c0) / TRK_RESYNC + 1) * TRK_RESYNC);
-                    while (c + 2 <= gend)
+                    f32x4 x0 = load_full(c);
+                    f32x4 x1 = load_full(min(c + 1, clast));
+                    while (c < cf1)
                         {
-                            const f32x4 xa = x0;
-                            x0 = load_full(min(c + 2, clast));
-                            process(std::true_type{}, c, xa);
-                            const f32x4 xb = x1;
-                            x1 = load_full(min(c + 3, clast));
-                            process(std::true_type{}, c + 1, xb);
-                            c += 2;
+                            if ((c - c0) % TRK_RESYNC == 0) resync(c);
+                            const int gend = min(cf1, c0 + ((c - c0) / TRK_RESYNC + 1) * TRK_RESYNC);
+                            while (c + 2 <= gend)
+                                {
+                                    const f32x4 xa = x0;
+                                    x0 = load_full(min(c + 2, clast));
+                                    process(std::true_type{}, c, xa);
+                                    const f32x4 xb = x1;
+                                    x1 = load_full(min(c + 3, clast));
+                                    process(std::true_type{}, c + 1, xb);
+                                    c += 2;
+                                }
+                            if (c < gend)
+                                {
+                                    // odd chunk left in this group: the buffers swap roles
+                                    const f32x4 xa = x0;
+                                    x0 = x1;
+                                    x1 = load_full(min(c + 2, clast));
+                                    process(std::true_type{}, c, xa);
+                                    ++c;
+                                }
                         }
-                    if (c < gend)
+                }
+            else
+                {
+                    // the same scheme with PF buffers: unrolled by PF, leftovers of a group one chunk at a time (the queue shifts)
+                    f32x4 x[PF];
+#pragma unroll
+                    for (int u = 0; u < PF; u++) x[u] = load_full(min(c + u, clast));
+                    while (c < cf1)
                         {
-                            // odd chunk left in this group: the buffers swap roles
-                            const f32x4 xa = x0;
-                            x0 = x1;
-                            x1 = load_full(min(c + 2, clast));
-                            process(std::true_type{}, c, xa);
-                            ++c;
+                            if ((c - c0) % TRK_RESYNC == 0) resync(c);
+                            const int gend = min(cf1, c0 + ((c - c0) / TRK_RESYNC + 1) * TRK_RESYNC);
+                            while (c + PF <= gend)
+                                {
+#pragma unroll
+                                    for (int u = 0; u < PF; u++)
+                                        {
+                                            const f32x4 xa = x[u];
+                                            x[u] = load_full(min(c + PF + u, clast));
+                                            process(std::true_type{}, c + u, xa);
+                                        }
+                                    c += PF;
+                                }
+                            while (c < gend)
+                                {
+                                    const f32x4 xa = x[0];
+#pragma unroll
+                                    for (int u = 0; u + 1 < PF; u++) x[u] = x[u + 1];
+                                    x[PF - 1] = load_full(min(c + PF, clast));
+                                    process(std::true_type{}, c, xa);
+                                    ++c;
+                                }
                         }
                 }
         }
@@ -421,7 +458,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 // With SC16 the returned pair holds the two 32-bit integer sums as bit patterns.
 // With DATA (pilot tracking) cd.code2 is the data component's replica: its prompt sum is returned to tid == NTAPS and the
 // window needs 2x the LDS floats.
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false>
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
     int lds_table_floats, float* lds)
 {
@@ -578,9 +615,9 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
     for (int t = 0; t < NACC; t++) accr[t] = acci[t] = 0.0f;
 
     if (windowed)
-        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS, DATA>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
+        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
     else
-        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
+        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread

@@ -294,18 +294,19 @@ def test_randomised_level1_call_sequences(gctx, oracle):
         mc.close()
 
 
-def _random_loop_case(rng):
+def _random_loop_case(rng, veml=None, pilot=None):
     """A random signal + loop configuration for the closed-loop state machine (synchronisation, extension, pilot)."""
     from test_loop_sync_gpu import _stream
-    veml = bool(rng.integers(0, 2))
+    force_pilot = pilot
+    veml = bool(rng.integers(0, 2)) if veml is None else veml
     spc = 2 if veml else 1
     L = int(rng.integers(150, 1200)) * spc            # code samples per period
     fs = float(rng.integers(2000, 5000)) * 1000.0     # 1 ms code period
     N = int(round(fs * 0.001))
     code = (rng.integers(0, 2, L) * 2 - 1).astype(np.float32)
     data_code = (rng.integers(0, 2, L) * 2 - 1).astype(np.float32)
-    kind = rng.choice(["secondary", "preamble", "single"])
-    pilot = kind == "secondary" and rng.uniform() < 0.7
+    kind = rng.choice(["secondary", "preamble", "single"]) if not force_pilot else "secondary"
+    pilot = (kind == "secondary" and rng.uniform() < 0.7) if force_pilot is None else force_pilot
     ext = int(rng.integers(1, 6))
     y = dict(extend_correlation_symbols=ext, track_pilot=pilot, pll_bw_narrow_hz=float(rng.uniform(8, 20)), dll_bw_narrow_hz=float(rng.uniform(0.5, 2.0)),
         early_late_space_narrow_chips=float(rng.uniform(0.1, 0.4)), very_early_late_space_narrow_chips=float(rng.uniform(0.45, 0.6)))
@@ -372,3 +373,27 @@ def test_randomised_loop_state_machine(gctx, oracle):
             raise AssertionError("case %d (seed %d): %s\nsync %r" % (case, seed, e, y)) from e
         reached[int(rec["state"][len(ref) - 1])] = reached.get(int(rec["state"][len(ref) - 1]), 0) + 1
     assert reached[3] + reached[4] >= 4, reached  # a fair share of the cases did synchronise
+    # several channels of one engine, each with its own signal, rates, synchronisation data and block length
+    for group in range(int(os.environ.get("GNSSCORR_FUZZ_LOOP_GROUPS", "6"))):
+        veml, pilot = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        cases = [_random_loop_case(rng, veml=veml, pilot=pilot) for _ in range(int(rng.integers(2, 6)))]
+        refs = [ref_run(oracle, x, code, conf, n_ep, sync=y, data_code=dc) for x, code, dc, conf, y, n_ep, _ in cases]
+        loop = gnsscorr.TrackingLoop(gctx, len(cases), max(c[1].size for c in cases))
+        keep = []
+        for ch, (x, code, dc, conf, y, n_ep, _) in enumerate(cases):
+            d = torch.from_numpy(x.view(np.float32)).cuda()
+            keep.append(d)
+            loop.set_input_dev(ch, d.data_ptr(), x.size)
+            loop.set_sync(ch, _sync(gnsscorr, y), dc)
+            loop.start(ch, _conf(gnsscorr, **conf), code)
+        n_max = max(c[5] for c in cases)
+        k = int(rng.integers(1, n_max))
+        rec = np.concatenate([loop.run(k), loop.run(n_max - k)], axis=1)
+        loop.close()
+        for ch, (x, code, dc, conf, y, n_ep, n_taps) in enumerate(cases):
+            try:
+                _compare(rec[ch, :len(refs[ch])], refs[ch], n_taps, tol=5e-3, abs_tol=2.2 * float(np.abs(x).max()))
+            except AssertionError as e:
+                raise AssertionError("group %d channel %d (seed %d): %s\nsync %r" % (group, ch, seed, e, y)) from e
+            # past the end of its input a channel produces invalid records and keeps its state
+            assert np.all(rec[ch, len(refs[ch]) + 1:]["valid"] == 0)

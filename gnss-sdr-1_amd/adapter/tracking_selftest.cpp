@@ -7,6 +7,7 @@
 // must converge to the truth.  Usage: tracking_selftest (needs a GPU).
 #include "dll_pll_tracking_adapters.h"
 #include "hip_glonass_ca_dll_pll_tracking.h"
+#include "hip_gps_l1_ca_dll_pll_c_aid_tracking.h"
 #include "pcps_acquisition_adapters.h"
 #include <cmath>
 #include <cstdio>
@@ -659,6 +660,94 @@ static void test_glonass_fdma_tracking()
         mean_doppler, fd, mean_nco, blk->cn0_db_hz(), blk->carrier_lock_test());
 }
 
+// gps_l1_ca_dll_pll_c_aid_tracking_cc / _sc: carrier-aided DLL; the telemetry decoder's preamble time stamp switches the block to
+// extend_correlation_ms-long coherent sums of its correlator history and to the narrow bandwidths
+template <class Item, class Block>
+static void c_aid_case(const char* name, std::shared_ptr<Block> blk, GpsL1CaDllPllCAidTrackingHip& trk, const std::vector<Item>& x, double fd, double cn0, double fs)
+{
+    Gnss_Synchro syn;
+    syn.System = 'G';
+    syn.Signal[0] = '1';
+    syn.Signal[1] = 'C';
+    syn.PRN = 9;
+    syn.Acq_delay_samples = 2001.0;
+    syn.Acq_doppler_hz = fd + 25.0;
+    syn.Acq_samplestamp_samples = 0;
+    trk.set_gnss_synchro(&syn);
+    trk.start_tracking();
+    size_t pos = 0;
+    int epochs = 0, updates_after = 0, valid_after = 0, len5 = 0;
+    Gnss_Synchro out;
+    double mean_doppler = 0.0;
+    int averaged = 0;
+    while (pos + blk->required_input_items() <= x.size() && blk->tracking_enabled())
+        {
+            int produced = 0;
+            pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+            if (epochs == 400) blk->set_preamble_timestamp_s(static_cast<double>(blk->sample_counter()) / fs);  // "a preamble started here"
+            if (epochs > 420)
+                {
+                    updates_after++;
+                    if (out.Flag_valid_symbol_output)
+                        {
+                            valid_after++;
+                            if (out.correlation_length_ms == 5) len5++;
+                        }
+                }
+            if (epochs >= 600)
+                {
+                    mean_doppler += blk->carrier_doppler_hz();
+                    averaged++;
+                }
+            epochs++;
+        }
+    mean_doppler /= std::max(1, averaged);
+    EXPECT(blk->last_status() == GC_OK, "%s: engine status %d (%s)", name, blk->last_status(), gc_last_error());
+    EXPECT(blk->tracking_enabled() && blk->events().empty() && epochs > 1100, "%s: lost lock after %d periods", name, epochs);
+    EXPECT(blk->preamble_synchronized(), "%s: extended integration never started", name);
+    // one loop update per 5 code periods once the preamble stamp is in
+    EXPECT(valid_after > 0 && len5 == valid_after && std::abs(5 * valid_after - updates_after) <= 6, "%s: %d loop updates in %d periods, %d of 5 ms", name, valid_after,
+        updates_after, len5);
+    EXPECT(averaged > 300 && std::fabs(mean_doppler - fd) < 2.0, "%s: mean Doppler %.2f Hz, truth %.2f", name, mean_doppler, fd);
+    EXPECT(std::fabs(blk->cn0_db_hz() - (cn0 + 7.0)) < 4.0 && blk->carrier_lock_test() > 0.85, "%s: C/N0 %.1f dB-Hz, lock test %.3f", name, blk->cn0_db_hz(),
+        blk->carrier_lock_test());
+    std::printf("%s: %d periods, %d loop updates of 5 ms after the preamble stamp, mean Doppler %.2f Hz (truth %.2f), C/N0 reading %.1f dB-Hz, lock test %.3f\n", name,
+        epochs, valid_after, mean_doppler, fd, blk->cn0_db_hz(), blk->carrier_lock_test());
+}
+
+static void test_gps_c_aid_tracking()
+{
+    const double fs = 4e6, fd = -1500.0, cn0 = 45.0;
+    std::vector<float> code(1023);
+    gc_gps_l1_ca_code_gen_float(code.data(), 9, 0);
+    auto x = synth(code, 1.023e6, 1575.42e6, fs, 4000 * 1200, fd, 1023.0 - 2001.0 * 1.023e6 / fs, cn0, 61);
+    {
+        InMemoryConfiguration config;
+        config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+        config.set_property("Tracking_1C.extend_correlation_ms", "5");
+        config.set_property("Tracking_1C.pll_bw_hz", "35.0");
+        config.set_property("Tracking_1C.pll_bw_narrow_hz", "15.0");
+        GpsL1CaDllPllCAidTrackingHip trk(&config, "Tracking_1C", 1, 1);
+        EXPECT(trk.implementation() == "GPS_L1_CA_DLL_PLL_C_Aid_Tracking_HIP" && trk.item_type() == "gr_complex" && trk.vector_length() == 4000, "C-aid adapter");
+        c_aid_case<gr_complex>("GPS L1 C/A C-aid tracking (gr_complex)", trk.block_gr_complex(), trk, x, fd, cn0, fs);
+    }
+    {
+        // cshort items: the 16-bit correlator (Cpu_Multicorrelator_16sc arithmetic); the stream is scaled so that five summed prompts stay inside int16, as the block sums them in lv_16sc_t
+        std::vector<std::complex<int16_t>> xs(x.size());
+        for (size_t i = 0; i < x.size(); i++)
+            xs[i] = std::complex<int16_t>(static_cast<int16_t>(std::lrint(x[i].real() * 10.0f)), static_cast<int16_t>(std::lrint(x[i].imag() * 10.0f)));
+        InMemoryConfiguration config;
+        config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+        config.set_property("Tracking_1C.item_type", "cshort");
+        config.set_property("Tracking_1C.extend_correlation_ms", "5");
+        config.set_property("Tracking_1C.pll_bw_hz", "35.0");
+        config.set_property("Tracking_1C.pll_bw_narrow_hz", "15.0");
+        GpsL1CaDllPllCAidTrackingHip trk(&config, "Tracking_1C", 1, 1);
+        EXPECT(trk.item_type() == "cshort" && trk.item_size() == 4, "C-aid adapter (cshort)");
+        c_aid_case<std::complex<int16_t>>("GPS L1 C/A C-aid tracking (cshort)", trk.block_cshort(), trk, xs, fd, cn0, fs);
+    }
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -705,6 +794,7 @@ int main()
     test_galileo_e5a_pilot();
     test_beidou_b3i_and_gps_l2c();
     test_glonass_fdma_tracking();
+    test_gps_c_aid_tracking();
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

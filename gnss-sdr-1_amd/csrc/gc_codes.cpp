@@ -712,4 +712,74 @@ gc_status gc_secondary_code(const char* signal, uint32_t prn, char* dest, int32_
     return GC_OK;
 }
 
+
+gc_status gc_loop_sync_for_signal(char system, const char* signal, uint32_t prn, int track_pilot, int extend_correlation_symbols, gc_loop_sync_conf* out)
+{
+    GC_REQUIRE(signal && out, "gc_loop_sync_for_signal: NULL argument");
+    GC_REQUIRE(extend_correlation_symbols >= 1, "gc_loop_sync_for_signal: extend_correlation_symbols must be >= 1");
+    const std::string sig(signal);
+    gc_loop_sync_conf y;
+    std::memset(&y, 0, sizeof y);
+    y.extend_correlation_symbols = extend_correlation_symbols;
+    y.bit_sync_min_time_s = 10.0f;
+    std::string secondary;
+    std::vector<int> preamble_bits;
+    int preamble_symbols_per_bit = 0;
+    if (system == 'G' && sig == "1C")
+        {
+            y.symbols_per_bit = 20;
+            preamble_bits = {1, 0, 0, 0, 1, 0, 1, 1};  // GPS_PREAMBLE
+            preamble_symbols_per_bit = 20;
+        }
+    else if (system == 'G' && sig == "2S")
+        y.symbols_per_bit = 1;
+    else if (system == 'G' && sig == "L5")
+        {
+            y.symbols_per_bit = 10;
+            y.track_pilot = track_pilot ? 1 : 0;
+            secondary = track_pilot ? "L5Q" : "L5I";
+        }
+    else if (system == 'E' && sig == "1B")
+        {
+            y.symbols_per_bit = 1;
+            y.track_pilot = track_pilot ? 1 : 0;
+            if (track_pilot) secondary = "1C";
+        }
+    else if (system == 'E' && sig == "5X")
+        {
+            y.symbols_per_bit = 20;
+            y.track_pilot = track_pilot ? 1 : 0;
+            if (track_pilot) secondary = "5Q";  // on the data component the secondary code is left to the telemetry decoder
+        }
+    else if (system == 'C' && (sig == "B1" || sig == "B3"))
+        {
+            if (prn > 0 && prn < 6)
+                {
+                    y.symbols_per_bit = 2;  // GEO satellites: D2, no NH code
+                    preamble_bits = {1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 0};
+                    preamble_symbols_per_bit = 2;
+                }
+            else
+                {
+                    y.symbols_per_bit = 20;
+                    secondary = sig;
+                }
+        }
+    else
+        return gc_fail(GC_ERR_INVALID, "gc_loop_sync_for_signal: unknown system / signal '%c' \"%s\"", system, signal);
+    if (!secondary.empty())
+        {
+            int32_t len = 0;
+            gc_status st = gc_secondary_code(secondary.c_str(), prn, y.secondary_code, (int32_t)sizeof y.secondary_code, &len);
+            if (st != GC_OK) return st;
+            y.secondary_code_length = len;
+        }
+    int n = 0;
+    for (int bit : preamble_bits)
+        for (int j = 0; j < preamble_symbols_per_bit; j++) y.preamble_symbols[n++] = bit ? 1 : -1;
+    y.preamble_length_symbols = n;
+    *out = y;
+    return GC_OK;
+}
+
 }  // extern "C"

@@ -202,6 +202,7 @@ API = {
     "gc_trk_loop_destroy": (C.c_int, [_vp]),
     "gc_trk_loop_set_input_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64]),
     "gc_trk_loop_set_sync": (C.c_int, [_vp, C.c_int, C.POINTER(LoopSyncConf), _fp, C.c_int]),
+    "gc_loop_sync_for_signal": (C.c_int, [C.c_char, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(LoopSyncConf)]),
     "gc_trk_loop_start": (C.c_int, [_vp, C.c_int, C.POINTER(LoopConf), _fp, C.c_int]),
     "gc_trk_loop_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "gc_trk_loop_run": (C.c_int, [_vp, C.c_int, _vp]),
@@ -396,6 +397,13 @@ def galileo_e5_a_code_gen_complex_primary(prn, signal):
 
 def galileo_e5_a_code_gen_complex_sampled(signal, prn, fs, chip_shift=0):
     return _sampled10230("gc_galileo_e5_a_code_gen_complex_sampled", fs, 10.23e6, signal.encode(), prn, fs, chip_shift)
+
+
+def loop_sync_for_signal(system, signal, prn, track_pilot=False, extend_correlation_symbols=1):
+    """gc_loop_sync_for_signal: the LoopSyncConf the block's constructor would derive for this signal and satellite."""
+    y = LoopSyncConf()
+    _check(load_library().gc_loop_sync_for_signal(system.encode(), signal.encode(), prn, int(bool(track_pilot)), extend_correlation_symbols, C.byref(y)))
+    return y
 
 
 def secondary_code(signal, prn=0):

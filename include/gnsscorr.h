@@ -331,6 +331,14 @@ typedef struct
     int8_t preamble_symbols[192];         /* +1 / -1 (d_preambles_symbols) */
 } gc_loop_sync_conf;
 
+/* Fills the signal-dependent part of a gc_loop_sync_conf the way the block's constructor and start_tracking do
+ * (dll_pll_veml_tracking.cc:113-336, :631-705): symbols per bit, secondary code, telemetry preamble for
+ * system / signal 'G' "1C" | "2S" | "L5", 'E' "1B" | "5X", 'C' "B1" | "B3" and the satellite `prn` (BeiDou GEO 1..5 broadcast D2;
+ * Galileo E5a-Q has one secondary code per PRN).  track_pilot is cleared for signals without a pilot component;
+ * bit_sync_min_time_s is set to the reference's 10 s; the narrow-stage fields are left for the caller (Dll_Pll_Conf). */
+gc_status gc_loop_sync_for_signal(char system, const char* signal, uint32_t prn, int track_pilot, int extend_correlation_symbols,
+    gc_loop_sync_conf* out);
+
 typedef struct gc_trk_loop gc_trk_loop;
 gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, gc_trk_loop** out);
 gc_status gc_trk_loop_destroy(gc_trk_loop* l);

@@ -153,3 +153,33 @@ def test_galileo_e5a_codes_are_the_icd_memory_codes():
         gnsscorr.secondary_code("5Q", 48)
     assert gnsscorr.secondary_code("1C") == "0011100000001010110110010" and gnsscorr.secondary_code("L5I") == "0000110101"
     assert gnsscorr.secondary_code("B3") == gnsscorr.secondary_code("L5Q") == "00000100110101001110"
+
+
+def test_loop_sync_for_signal_mirrors_the_block_constructor():
+    """gc_loop_sync_for_signal: what dll_pll_veml_tracking's constructor / start_tracking derive per signal (:113-336, :631-705)."""
+    import gnsscorr
+    y = gnsscorr.loop_sync_for_signal("G", "1C", 7, track_pilot=True, extend_correlation_symbols=20)
+    assert (y.symbols_per_bit, y.secondary_code_length, y.preamble_length_symbols, y.track_pilot, y.extend_correlation_symbols) == (20, 0, 160, 0, 20)
+    pre = list(y.preamble_symbols)[:160]
+    assert pre == [s for b in (1, 0, 0, 0, 1, 0, 1, 1) for s in [1 if b else -1] * 20] and y.bit_sync_min_time_s == 10.0
+    y = gnsscorr.loop_sync_for_signal("G", "2S", 3)
+    assert (y.symbols_per_bit, y.secondary_code_length, y.preamble_length_symbols) == (1, 0, 0)
+    y = gnsscorr.loop_sync_for_signal("G", "L5", 3, track_pilot=True)
+    assert (y.symbols_per_bit, y.track_pilot, y.secondary_code.decode()) == (10, 1, "00000100110101001110")
+    assert gnsscorr.loop_sync_for_signal("G", "L5", 3).secondary_code.decode() == "0000110101"
+    y = gnsscorr.loop_sync_for_signal("E", "1B", 11, track_pilot=True, extend_correlation_symbols=4)
+    assert (y.symbols_per_bit, y.track_pilot, y.secondary_code_length, y.secondary_code.decode()) == (1, 1, 25, "0011100000001010110110010")
+    assert gnsscorr.loop_sync_for_signal("E", "1B", 11).secondary_code_length == 0
+    y = gnsscorr.loop_sync_for_signal("E", "5X", 12, track_pilot=True)
+    assert y.secondary_code_length == 100 and y.secondary_code.decode() == gnsscorr.secondary_code("5Q", 12)
+    assert gnsscorr.loop_sync_for_signal("E", "5X", 12).secondary_code_length == 0  # left to the telemetry decoder
+    for sig in ("B1", "B3"):
+        y = gnsscorr.loop_sync_for_signal("C", sig, 20)
+        assert (y.symbols_per_bit, y.secondary_code.decode(), y.preamble_length_symbols) == (20, "00000100110101001110", 0)
+        geo = gnsscorr.loop_sync_for_signal("C", sig, 3)
+        assert (geo.symbols_per_bit, geo.secondary_code_length, geo.preamble_length_symbols) == (2, 0, 22)
+        assert list(geo.preamble_symbols)[:22] == [s for b in (1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 0) for s in [1 if b else -1] * 2]
+    with pytest.raises(gnsscorr.GnsscorrError, match="unknown system"):
+        gnsscorr.loop_sync_for_signal("R", "1G", 1)
+    with pytest.raises(gnsscorr.GnsscorrError, match="no E5a-Q secondary code"):
+        gnsscorr.loop_sync_for_signal("E", "5X", 49, track_pilot=True)

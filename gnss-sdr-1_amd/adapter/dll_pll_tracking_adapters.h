@@ -14,11 +14,13 @@
 #define GNSSCORR_DLL_PLL_TRACKING_ADAPTERS_H_
 
 #include "hip_dll_pll_veml_tracking.h"
+#include "hip_dll_pll_veml_tracking_dev.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 
 namespace gnsscorr
 {
@@ -67,7 +69,9 @@ inline const TrkSignalTraits& trk_traits(TrkSignal s)
 }
 }  // namespace gnsscorr
 
-template <gnsscorr::TrkSignal SIG>
+//! Block: hip_dll_pll_veml_tracking (one level-1 correlator call per code period, host loop maths) or
+//! hip_dll_pll_veml_tracking_dev (every complete code period of a work() call in one launch of the device loop)
+template <gnsscorr::TrkSignal SIG, class Block = hip_dll_pll_veml_tracking>
 class DllPllTrackingHip : public TrackingInterface
 {
 public:
@@ -129,11 +133,15 @@ public:
         trk_param.max_lock_fail = configuration->property(role + ".max_lock_fail", 50);
         trk_param.carrier_lock_th = configuration->property(role + ".carrier_lock_th", t.carrier_lock_th);
         conf_ = trk_param;
-        tracking_ = std::make_shared<hip_dll_pll_veml_tracking>(trk_param);
+        tracking_ = std::make_shared<Block>(trk_param);
     }
 
     std::string role() override { return role_; }
-    std::string implementation() override { return gnsscorr::trk_traits(SIG).implementation; }
+    std::string implementation() override
+    {
+        const std::string name = gnsscorr::trk_traits(SIG).implementation;
+        return std::is_same<Block, hip_dll_pll_veml_tracking>::value ? name : name + "_DEV";
+    }
     size_t item_size() override { return sizeof(gr_complex); }
 
     void start_tracking() override { tracking_->start_tracking(); }
@@ -146,11 +154,11 @@ public:
     void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) override { tracking_->set_gnss_synchro(p_gnss_synchro); }
 
     //! the block (get_left_block()/get_right_block() in the reference)
-    std::shared_ptr<hip_dll_pll_veml_tracking> block() { return tracking_; }
+    std::shared_ptr<Block> block() { return tracking_; }
     const Dll_Pll_Conf& conf() const { return conf_; }
 
 private:
-    std::shared_ptr<hip_dll_pll_veml_tracking> tracking_;
+    std::shared_ptr<Block> tracking_;
     Dll_Pll_Conf conf_;
     std::string role_;
     unsigned int channel_ = 0;
@@ -165,5 +173,13 @@ using GpsL2MDllPllTrackingHip = DllPllTrackingHip<gnsscorr::TrkSignal::GPS_L2_M>
 using GpsL5DllPllTrackingHip = DllPllTrackingHip<gnsscorr::TrkSignal::GPS_L5>;
 using GalileoE5aDllPllTrackingHip = DllPllTrackingHip<gnsscorr::TrkSignal::GALILEO_E5A>;
 using BeidouB3iDllPllTrackingHip = DllPllTrackingHip<gnsscorr::TrkSignal::BEIDOU_B3I>;
+//! the same adapters on the device loop ("..._HIP_DEV")
+using GpsL1CaDllPllTrackingHipDev = DllPllTrackingHip<gnsscorr::TrkSignal::GPS_L1_CA, hip_dll_pll_veml_tracking_dev>;
+using GalileoE1DllPllVemlTrackingHipDev = DllPllTrackingHip<gnsscorr::TrkSignal::GALILEO_E1, hip_dll_pll_veml_tracking_dev>;
+using BeidouB1iDllPllTrackingHipDev = DllPllTrackingHip<gnsscorr::TrkSignal::BEIDOU_B1I, hip_dll_pll_veml_tracking_dev>;
+using GpsL2MDllPllTrackingHipDev = DllPllTrackingHip<gnsscorr::TrkSignal::GPS_L2_M, hip_dll_pll_veml_tracking_dev>;
+using GpsL5DllPllTrackingHipDev = DllPllTrackingHip<gnsscorr::TrkSignal::GPS_L5, hip_dll_pll_veml_tracking_dev>;
+using GalileoE5aDllPllTrackingHipDev = DllPllTrackingHip<gnsscorr::TrkSignal::GALILEO_E5A, hip_dll_pll_veml_tracking_dev>;
+using BeidouB3iDllPllTrackingHipDev = DllPllTrackingHip<gnsscorr::TrkSignal::BEIDOU_B3I, hip_dll_pll_veml_tracking_dev>;
 
 #endif  // GNSSCORR_DLL_PLL_TRACKING_ADAPTERS_H_

@@ -748,6 +748,97 @@ static void test_gps_c_aid_tracking()
     }
 }
 
+// The same block on the device loop: a work() call brings a chunk of items and gets back one Gnss_Synchro per complete code
+// period -- against the host-loop block fed the same stream: identical block boundaries and states, Doppler within a fraction of a Hz.
+static void test_device_loop_block()
+{
+    const double fs = 4e6, fd = 2210.0, cn0 = 47.0, delay_samples = 3456.0;
+    Component b, c;
+    b.code.resize(8184);
+    c.code.resize(8184);
+    char sb[3] = "1B", sc[3] = "1C";
+    gc_galileo_e1_code_gen_sinboc11_float(b.code.data(), sb, 19);
+    gc_galileo_e1_code_gen_sinboc11_float(c.code.data(), sc, 19);
+    std::mt19937 gen(5);
+    for (int i = 0; i < 500; i++) b.symbols.push_back((gen() & 1u) ? 1.0f : -1.0f);
+    for (char ch : std::string("0011100000001010110110010")) c.symbols.push_back(ch == '0' ? 1.0f : -1.0f);
+    auto x = synth_symbols({b, c}, 2.046e6, 1575.42e6, fs, 16000 * 160, fd, delay_samples, cn0, 21);
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+    config.set_property("Tracking_1B.track_pilot", "true");
+    config.set_property("Tracking_1B.extend_correlation_symbols", "4");
+    config.set_property("Tracking_1B.pll_bw_hz", "25.0");
+    config.set_property("Tracking_1B.dll_bw_hz", "2.0");
+    config.set_property("Tracking_1B.pll_bw_narrow_hz", "10.0");
+    config.set_property("Tracking_1B.dll_bw_narrow_hz", "0.5");
+    config.set_property("Tracking_1B.early_late_space_narrow_chips", "0.1");
+    config.set_property("Tracking_1B.very_early_late_space_narrow_chips", "0.5");
+    config.set_property("Tracking_1B.pull_in_time_s", "0");
+    Gnss_Synchro syn;
+    syn.System = 'E';
+    syn.Signal[0] = '1';
+    syn.Signal[1] = 'B';
+    syn.PRN = 19;
+    syn.Acq_delay_samples = delay_samples;
+    syn.Acq_doppler_hz = fd - 1.0;
+    syn.Acq_samplestamp_samples = 0;
+    // host-loop block: one period per call
+    std::vector<Gnss_Synchro> host;
+    {
+        GalileoE1DllPllVemlTrackingHip trk(&config, "Tracking_1B", 1, 1);
+        trk.set_gnss_synchro(&syn);
+        trk.start_tracking();
+        auto blk = trk.block();
+        size_t pos = 0;
+        Gnss_Synchro out;
+        while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+            {
+                int produced = 0;
+                pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+                if (produced) host.push_back(out);
+            }
+    }
+    // device-loop block: chunks of uneven size, as a scheduler would deliver them
+    GalileoE1DllPllVemlTrackingHipDev trk(&config, "Tracking_1B", 1, 1);
+    EXPECT(trk.implementation() == "Galileo_E1_DLL_PLL_VEML_Tracking_HIP_DEV", "device adapter name %s", trk.implementation().c_str());
+    trk.set_gnss_synchro(&syn);
+    auto blk = trk.block();
+    EXPECT(blk->last_status() == GC_OK, "device block: status %d (%s)", blk->last_status(), gc_last_error());
+    trk.start_tracking();
+    std::vector<Gnss_Synchro> dev, outs(80);
+    size_t pos = 0;
+    int calls = 0;
+    std::mt19937 chunker(7);
+    while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
+        {
+            // the scheduler shows between 2 and 40 periods' worth of items, including those the block did not consume last time
+            const size_t avail = std::min<size_t>(x.size() - pos, 16000 * (2 + chunker() % 39) + chunker() % 5000);
+            int produced = 0;
+            const int used = blk->work(x.data() + pos, static_cast<int>(avail), outs.data(), static_cast<int>(outs.size()), &produced);
+            EXPECT(blk->last_status() == GC_OK, "device block: status %d (%s)", blk->last_status(), gc_last_error());
+            if (blk->last_status() != GC_OK) break;
+            for (int k = 0; k < produced; k++) dev.push_back(outs[k]);
+            pos += used;
+            calls++;
+            if (used == 0 && produced == 0 && avail == x.size() - pos) break;  // the tail is shorter than a period
+        }
+    EXPECT(dev.size() + 1 >= host.size() && host.size() > 150, "device block: %zu outputs, host block %zu", dev.size(), host.size());
+    size_t same_counter = 0;
+    double worst_doppler = 0.0, worst_prompt = 0.0;
+    const size_t n = std::min(dev.size(), host.size());
+    for (size_t k = 0; k < n; k++)
+        {
+            if (dev[k].Tracking_sample_counter == host[k].Tracking_sample_counter) same_counter++;
+            worst_doppler = std::max(worst_doppler, std::fabs(dev[k].Carrier_Doppler_hz - host[k].Carrier_Doppler_hz));
+            worst_prompt = std::max(worst_prompt, std::fabs(dev[k].Prompt_I - host[k].Prompt_I) / (std::fabs(host[k].Prompt_I) + 50.0));
+        }
+    EXPECT(same_counter == n, "device block: %zu of %zu block boundaries agree with the host block", same_counter, n);
+    EXPECT(worst_doppler < 0.2 && worst_prompt < 0.02, "device block: Doppler differs by %.3f Hz, prompt by %.4f", worst_doppler, worst_prompt);
+    EXPECT(blk->state() == 3 || blk->state() == 4, "device block: state %d", blk->state());
+    std::printf("device-loop block: %zu Gnss_Synchro in %d work() calls (host-loop block: %zu in as many calls), boundaries identical, Doppler within %.3f Hz\n",
+        dev.size(), calls, host.size(), worst_doppler);
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -795,6 +886,7 @@ int main()
     test_beidou_b3i_and_gps_l2c();
     test_glonass_fdma_tracking();
     test_gps_c_aid_tracking();
+    test_device_loop_block();
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

@@ -9,6 +9,7 @@
 #include "hip_glonass_ca_dll_pll_tracking.h"
 #include "hip_gps_l1_ca_dll_pll_c_aid_tracking.h"
 #include "pcps_acquisition_adapters.h"
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -784,6 +785,7 @@ static void test_device_loop_block()
     syn.Acq_samplestamp_samples = 0;
     // host-loop block: one period per call
     std::vector<Gnss_Synchro> host;
+    double host_s = 0.0, dev_s = 0.0;
     {
         GalileoE1DllPllVemlTrackingHip trk(&config, "Tracking_1B", 1, 1);
         trk.set_gnss_synchro(&syn);
@@ -791,12 +793,14 @@ static void test_device_loop_block()
         auto blk = trk.block();
         size_t pos = 0;
         Gnss_Synchro out;
+        const auto t0 = std::chrono::steady_clock::now();
         while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
             {
                 int produced = 0;
                 pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
                 if (produced) host.push_back(out);
             }
+        host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     // device-loop block: chunks of uneven size, as a scheduler would deliver them
     GalileoE1DllPllVemlTrackingHipDev trk(&config, "Tracking_1B", 1, 1);
@@ -809,6 +813,7 @@ static void test_device_loop_block()
     size_t pos = 0;
     int calls = 0;
     std::mt19937 chunker(7);
+    const auto t1 = std::chrono::steady_clock::now();
     while (pos + blk->required_input_items() <= x.size() && blk->state() != 0)
         {
             // the scheduler shows between 2 and 40 periods' worth of items, including those the block did not consume last time
@@ -822,6 +827,7 @@ static void test_device_loop_block()
             calls++;
             if (used == 0 && produced == 0 && avail == x.size() - pos) break;  // the tail is shorter than a period
         }
+    dev_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     EXPECT(dev.size() + 1 >= host.size() && host.size() > 150, "device block: %zu outputs, host block %zu", dev.size(), host.size());
     size_t same_counter = 0;
     double worst_doppler = 0.0, worst_prompt = 0.0;
@@ -835,8 +841,9 @@ static void test_device_loop_block()
     EXPECT(same_counter == n, "device block: %zu of %zu block boundaries agree with the host block", same_counter, n);
     EXPECT(worst_doppler < 0.2 && worst_prompt < 0.02, "device block: Doppler differs by %.3f Hz, prompt by %.4f", worst_doppler, worst_prompt);
     EXPECT(blk->state() == 3 || blk->state() == 4, "device block: state %d", blk->state());
-    std::printf("device-loop block: %zu Gnss_Synchro in %d work() calls (host-loop block: %zu in as many calls), boundaries identical, Doppler within %.3f Hz\n",
-        dev.size(), calls, host.size(), worst_doppler);
+    std::printf("device-loop block: %zu Gnss_Synchro in %d work() calls, %.1f ms (host-loop block: %zu in as many calls, %.1f ms) for %.0f ms of signal; "
+                "boundaries identical, Doppler within %.3f Hz\n",
+        dev.size(), calls, dev_s * 1e3, host.size(), host_s * 1e3, x.size() / fs * 1e3, worst_doppler);
 }
 
 static void test_loss_of_lock()

@@ -44,6 +44,102 @@ inline bool trk_signal_constants(char system, const std::string& signal, TrkSign
     else return false;
     return true;
 }
+
+/*! start_tracking (:549-747) of one channel of a device loop: replicas, synchronisation data, loop start.  `sample_counter` is the
+ *  stream position the channel starts consuming at (the block's d_sample_counter). */
+inline gc_status loop_start_channel(gc_trk_loop* loop, int ch, const Dll_Pll_Conf& trk_parameters, const TrkSignalConstants& sig, const Gnss_Synchro& acq,
+    uint64_t sample_counter, float bit_sync_min_time_s = 10.0f)
+{
+    const uint32_t prn = acq.PRN;
+    const std::string signal(trk_parameters.signal);
+    const int code_len = static_cast<int>(sig.code_length_chips * sig.code_samples_per_chip);
+    std::vector<float> code(code_len), data_code(code_len);
+    const bool pilot = trk_parameters.track_pilot && sig.has_pilot;
+    gc_status st = GC_OK;
+    // the replica the loop runs on, and the data component's when the loop runs on the pilot (:566-705)
+    if (trk_parameters.system == 'G' && signal == "1C") st = gc_gps_l1_ca_code_gen_float(code.data(), static_cast<int32_t>(prn), 0);
+    else if (trk_parameters.system == 'G' && signal == "2S") st = gc_gps_l2c_m_code_gen_float(code.data(), prn);
+    else if (trk_parameters.system == 'G' && signal == "L5")
+        {
+            st = pilot ? gc_gps_l5q_code_gen_float(code.data(), prn) : gc_gps_l5i_code_gen_float(code.data(), prn);
+            if (pilot && st == GC_OK) st = gc_gps_l5i_code_gen_float(data_code.data(), prn);
+        }
+    else if (trk_parameters.system == 'E' && signal == "1B")
+        {
+            st = gc_galileo_e1_code_gen_sinboc11_float(code.data(), pilot ? "1C" : "1B", prn);
+            if (pilot && st == GC_OK) st = gc_galileo_e1_code_gen_sinboc11_float(data_code.data(), "1B", prn);
+        }
+    else if (trk_parameters.system == 'E' && signal == "5X")
+        {
+            std::vector<float> aux(2 * code_len);
+            st = gc_galileo_e5_a_code_gen_complex_primary(aux.data(), static_cast<int32_t>(prn), "5X");
+            for (int i = 0; i < code_len; i++)
+                {
+                    code[i] = pilot ? aux[2 * i + 1] : aux[2 * i];
+                    data_code[i] = aux[2 * i];
+                }
+        }
+    else if (trk_parameters.system == 'C' && signal == "B1") st = gc_beidou_b1i_code_gen_float(code.data(), static_cast<int32_t>(prn), 0);
+    else st = gc_beidou_b3i_code_gen_float(code.data(), static_cast<int32_t>(prn), 0);
+    if (st != GC_OK) return st;
+    gc_loop_sync_conf y;
+    st = gc_loop_sync_for_signal(trk_parameters.system, trk_parameters.signal, prn, pilot ? 1 : 0, std::max(1, trk_parameters.extend_correlation_symbols), &y);
+    if (st != GC_OK) return st;
+    y.bit_sync_min_time_s = bit_sync_min_time_s;
+    y.pll_bw_narrow_hz = trk_parameters.pll_bw_narrow_hz;
+    y.dll_bw_narrow_hz = trk_parameters.dll_bw_narrow_hz;
+    y.early_late_space_narrow_chips = trk_parameters.early_late_space_narrow_chips;
+    y.very_early_late_space_narrow_chips = trk_parameters.very_early_late_space_narrow_chips;
+    st = gc_trk_loop_set_sync(loop, ch, &y, pilot ? data_code.data() : nullptr, code_len);
+    if (st != GC_OK) return st;
+    gc_loop_conf c;
+    std::memset(&c, 0, sizeof c);
+    c.fs_in = trk_parameters.fs_in;
+    c.signal_carrier_freq_hz = sig.carrier_freq_hz;
+    c.code_chip_rate_hz = sig.code_chip_rate_hz;
+    c.code_period_s = sig.code_period_s;
+    c.carrier_lock_th = trk_parameters.carrier_lock_th;
+    c.acq_delay_samples = acq.Acq_delay_samples;
+    c.acq_doppler_hz = acq.Acq_doppler_hz;
+    c.acq_samplestamp_samples = acq.Acq_samplestamp_samples;
+    c.sample_counter = sample_counter;
+    c.code_length_chips = sig.code_length_chips;
+    c.code_samples_per_chip = sig.code_samples_per_chip;
+    c.vector_length = trk_parameters.vector_length;
+    c.pull_in_time_s = trk_parameters.pull_in_time_s;
+    c.veml = sig.veml ? 1 : 0;
+    c.pll_filter_order = trk_parameters.pll_filter_order;
+    c.dll_filter_order = trk_parameters.dll_filter_order;
+    c.enable_fll_pull_in = trk_parameters.enable_fll_pull_in ? 1 : 0;
+    c.enable_fll_steady_state = trk_parameters.enable_fll_steady_state ? 1 : 0;
+    c.cn0_samples = trk_parameters.cn0_samples;
+    c.cn0_min = trk_parameters.cn0_min;
+    c.max_lock_fail = trk_parameters.max_lock_fail;
+    c.pll_bw_hz = trk_parameters.pll_bw_hz;
+    c.dll_bw_hz = trk_parameters.dll_bw_hz;
+    c.fll_bw_hz = trk_parameters.fll_bw_hz;
+    c.early_late_space_chips = trk_parameters.early_late_space_chips;
+    c.very_early_late_space_chips = trk_parameters.very_early_late_space_chips;
+    c.high_dyn_smoother_length = trk_parameters.high_dyn ? std::min(16u, std::max(1u, trk_parameters.smoother_length)) : 0u;
+    return gc_trk_loop_start(loop, ch, &c, code.data(), code_len);
+}
+
+//! what a valid period hands to the telemetry decoder (:1693-1725, :1898-1906), from the device loop's record
+inline Gnss_Synchro synchro_from_record(const gc_loop_record& r, const Gnss_Synchro& acq, const TrkSignalConstants& sig, bool interchange_iq, double fs_in)
+{
+    Gnss_Synchro s = acq;
+    s.Prompt_I = static_cast<double>(interchange_iq ? r.prompt_data[1] : r.prompt_data[0]);
+    s.Prompt_Q = static_cast<double>(interchange_iq ? r.prompt_data[0] : r.prompt_data[1]);
+    s.Code_phase_samples = r.rem_code_phase_samples;
+    s.Carrier_phase_rads = r.acc_carrier_phase_rad;
+    s.Carrier_Doppler_hz = r.carrier_doppler_hz;
+    s.CN0_dB_hz = r.cn0_db_hz;
+    s.correlation_length_ms = sig.correlation_length_ms;
+    s.Flag_valid_symbol_output = true;
+    s.fs = static_cast<int64_t>(fs_in);
+    s.Tracking_sample_counter = r.sample_counter;
+    return s;
+}
 }  // namespace gnsscorr
 
 class hip_dll_pll_veml_tracking_dev
@@ -88,77 +184,8 @@ public:
     {
         std::lock_guard<std::mutex> l(d_setlock);
         if (d_status != GC_OK || !d_ok) return;
-        const uint32_t prn = d_acquisition_gnss_synchro->PRN;
-        const std::string signal(trk_parameters.signal);
-        const int code_len = static_cast<int>(d_sig.code_length_chips * d_sig.code_samples_per_chip);
-        std::vector<float> code(code_len), data_code(code_len);
         const bool pilot = trk_parameters.track_pilot;
-        // the replica the loop runs on, and the data component's when the loop runs on the pilot (:566-705)
-        if (trk_parameters.system == 'G' && signal == "1C") d_status = gc_gps_l1_ca_code_gen_float(code.data(), static_cast<int32_t>(prn), 0);
-        else if (trk_parameters.system == 'G' && signal == "2S") d_status = gc_gps_l2c_m_code_gen_float(code.data(), prn);
-        else if (trk_parameters.system == 'G' && signal == "L5")
-            {
-                d_status = pilot ? gc_gps_l5q_code_gen_float(code.data(), prn) : gc_gps_l5i_code_gen_float(code.data(), prn);
-                if (pilot && d_status == GC_OK) d_status = gc_gps_l5i_code_gen_float(data_code.data(), prn);
-            }
-        else if (trk_parameters.system == 'E' && signal == "1B")
-            {
-                d_status = gc_galileo_e1_code_gen_sinboc11_float(code.data(), pilot ? "1C" : "1B", prn);
-                if (pilot && d_status == GC_OK) d_status = gc_galileo_e1_code_gen_sinboc11_float(data_code.data(), "1B", prn);
-            }
-        else if (trk_parameters.system == 'E' && signal == "5X")
-            {
-                std::vector<float> aux(2 * code_len);
-                d_status = gc_galileo_e5_a_code_gen_complex_primary(aux.data(), static_cast<int32_t>(prn), "5X");
-                for (int i = 0; i < code_len; i++)
-                    {
-                        code[i] = pilot ? aux[2 * i + 1] : aux[2 * i];
-                        data_code[i] = aux[2 * i];
-                    }
-            }
-        else if (trk_parameters.system == 'C' && signal == "B1") d_status = gc_beidou_b1i_code_gen_float(code.data(), static_cast<int32_t>(prn), 0);
-        else d_status = gc_beidou_b3i_code_gen_float(code.data(), static_cast<int32_t>(prn), 0);
-        if (d_status != GC_OK) return;
-        gc_loop_sync_conf y;
-        d_status = gc_loop_sync_for_signal(trk_parameters.system, trk_parameters.signal, prn, pilot ? 1 : 0, trk_parameters.extend_correlation_symbols, &y);
-        if (d_status != GC_OK) return;
-        y.bit_sync_min_time_s = d_bit_sync_min_time_s;
-        y.pll_bw_narrow_hz = trk_parameters.pll_bw_narrow_hz;
-        y.dll_bw_narrow_hz = trk_parameters.dll_bw_narrow_hz;
-        y.early_late_space_narrow_chips = trk_parameters.early_late_space_narrow_chips;
-        y.very_early_late_space_narrow_chips = trk_parameters.very_early_late_space_narrow_chips;
-        d_status = gc_trk_loop_set_sync(d_loop, 0, &y, pilot ? data_code.data() : nullptr, code_len);
-        if (d_status != GC_OK) return;
-        gc_loop_conf c;
-        std::memset(&c, 0, sizeof c);
-        c.fs_in = trk_parameters.fs_in;
-        c.signal_carrier_freq_hz = d_sig.carrier_freq_hz;
-        c.code_chip_rate_hz = d_sig.code_chip_rate_hz;
-        c.code_period_s = d_sig.code_period_s;
-        c.carrier_lock_th = trk_parameters.carrier_lock_th;
-        c.acq_delay_samples = d_acquisition_gnss_synchro->Acq_delay_samples;
-        c.acq_doppler_hz = d_acquisition_gnss_synchro->Acq_doppler_hz;
-        c.acq_samplestamp_samples = d_acquisition_gnss_synchro->Acq_samplestamp_samples;
-        c.sample_counter = d_sample_counter;  // ring addressing: the channel starts at the block's own sample counter
-        c.code_length_chips = d_sig.code_length_chips;
-        c.code_samples_per_chip = d_sig.code_samples_per_chip;
-        c.vector_length = trk_parameters.vector_length;
-        c.pull_in_time_s = trk_parameters.pull_in_time_s;
-        c.veml = d_sig.veml ? 1 : 0;
-        c.pll_filter_order = trk_parameters.pll_filter_order;
-        c.dll_filter_order = trk_parameters.dll_filter_order;
-        c.enable_fll_pull_in = trk_parameters.enable_fll_pull_in ? 1 : 0;
-        c.enable_fll_steady_state = trk_parameters.enable_fll_steady_state ? 1 : 0;
-        c.cn0_samples = trk_parameters.cn0_samples;
-        c.cn0_min = trk_parameters.cn0_min;
-        c.max_lock_fail = trk_parameters.max_lock_fail;
-        c.pll_bw_hz = trk_parameters.pll_bw_hz;
-        c.dll_bw_hz = trk_parameters.dll_bw_hz;
-        c.fll_bw_hz = trk_parameters.fll_bw_hz;
-        c.early_late_space_chips = trk_parameters.early_late_space_chips;
-        c.very_early_late_space_chips = trk_parameters.very_early_late_space_chips;
-        c.high_dyn_smoother_length = trk_parameters.high_dyn ? std::min(16u, std::max(1u, trk_parameters.smoother_length)) : 0u;
-        d_status = gc_trk_loop_start(d_loop, 0, &c, code.data(), code_len);
+        d_status = gnsscorr::loop_start_channel(d_loop, 0, trk_parameters, d_sig, *d_acquisition_gnss_synchro, d_sample_counter, d_bit_sync_min_time_s);
         d_interchange_iq = pilot && d_sig.interchange_iq_with_pilot;
         d_state = d_status == GC_OK ? 1 : 0;
     }
@@ -220,19 +247,7 @@ public:
                 d_last = r;
                 if (r.valid)
                     {
-                        Gnss_Synchro s = *d_acquisition_gnss_synchro;
-                        const float pi = d_interchange_iq ? r.prompt_data[1] : r.prompt_data[0];
-                        const float pq = d_interchange_iq ? r.prompt_data[0] : r.prompt_data[1];
-                        s.Prompt_I = static_cast<double>(pi);
-                        s.Prompt_Q = static_cast<double>(pq);
-                        s.Code_phase_samples = r.rem_code_phase_samples;
-                        s.Carrier_phase_rads = r.acc_carrier_phase_rad;
-                        s.Carrier_Doppler_hz = r.carrier_doppler_hz;
-                        s.CN0_dB_hz = r.cn0_db_hz;
-                        s.correlation_length_ms = d_sig.correlation_length_ms;
-                        s.Flag_valid_symbol_output = true;
-                        s.fs = static_cast<int64_t>(trk_parameters.fs_in);
-                        s.Tracking_sample_counter = r.sample_counter;
+                        const Gnss_Synchro s = gnsscorr::synchro_from_record(r, *d_acquisition_gnss_synchro, d_sig, d_interchange_iq, trk_parameters.fs_in);
                         out[(*produced)++] = s;
                     }
                 if (r.state == 0)

@@ -8,6 +8,7 @@
 #include "dll_pll_tracking_adapters.h"
 #include "hip_glonass_ca_dll_pll_tracking.h"
 #include "hip_gps_l1_ca_dll_pll_c_aid_tracking.h"
+#include "hip_tracking_group.h"
 #include "pcps_acquisition_adapters.h"
 #include <chrono>
 #include <cmath>
@@ -846,6 +847,112 @@ static void test_device_loop_block()
         dev.size(), calls, dev_s * 1e3, host.size(), host_s * 1e3, x.size() / fs * 1e3, worst_doppler);
 }
 
+// All channels of a signal as one object on one RF stream ring: four satellites in the stream, six slots, hand-overs at different
+// times, one slot pointed at a satellite that is not there (it loses lock and frees itself), one launch per pushed block.
+static void test_tracking_group()
+{
+    const double fs = 4e6;
+    const int prns[4] = {3, 11, 19, 27};
+    const double dopplers[4] = {1200.0, -2500.0, 300.0, 3800.0};
+    const double delays[4] = {100.0, 1500.0, 2900.0, 3999.0};
+    const size_t n = 4000 * 1500;  // the lock detector only counts once the pull-in transitory (at least 1 s) is over
+    std::vector<gr_complex> x(n, gr_complex(0, 0));
+    for (int k = 0; k < 4; k++)
+        {
+            std::vector<float> code(1023);
+            gc_gps_l1_ca_code_gen_float(code.data(), prns[k], 0);
+            // noise once (first satellite), signal only for the others
+            auto xs = synth(code, 1.023e6, 1575.42e6, fs, n, dopplers[k], 1023.0 - delays[k] * 1.023e6 / fs, 46.0, 70 + k);
+            if (k == 0)
+                x = xs;
+            else
+                {
+                    auto noise_free = synth(code, 1.023e6, 1575.42e6, fs, n, dopplers[k], 1023.0 - delays[k] * 1.023e6 / fs, 46.0, 70 + k);
+                    // subtract this call's own noise by regenerating it at -infinity dB
+                    auto only_noise = synth(code, 1.023e6, 1575.42e6, fs, n, dopplers[k], 1023.0 - delays[k] * 1.023e6 / fs, -300.0, 70 + k);
+                    for (size_t i = 0; i < n; i++) x[i] += noise_free[i] - only_noise[i];
+                }
+        }
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+    config.set_property("Tracking_1C.pll_bw_hz", "35.0");
+    config.set_property("Tracking_1C.pull_in_time_s", "0");
+    config.set_property("Tracking_1C.max_lock_fail", "5");
+    config.set_property("Tracking_1C.cn0_samples", "10");
+    GpsL1CaDllPllTrackingHip conf_source(&config, "Tracking_1C", 1, 1);  // the adapter turns the configuration into a Dll_Pll_Conf
+    const Dll_Pll_Conf conf = conf_source.conf();
+    gc_ctx* ctx = nullptr;
+    gc_stream* ring = nullptr;
+    EXPECT(gc_ctx_create(0, &ctx) == GC_OK, "group: context");
+    EXPECT(gc_stream_create(ctx, GC_IQ_F32, 4000 * 128, 8000, &ring) == GC_OK, "group: ring (%s)", gc_last_error());
+    {
+        hip_tracking_group group(ctx, ring, conf, 6);
+        EXPECT(group.last_status() == GC_OK, "group: status %d (%s)", group.last_status(), gc_last_error());
+        auto acq_of = [&](int k, uint64_t stamp) {
+            Gnss_Synchro a;
+            a.System = 'G';
+            a.Signal[0] = '1';
+            a.Signal[1] = 'C';
+            a.PRN = prns[k];
+            a.Acq_delay_samples = delays[k];
+            a.Acq_doppler_hz = dopplers[k] + 30.0;
+            a.Acq_samplestamp_samples = stamp;
+            return a;
+        };
+        std::vector<std::vector<Gnss_Synchro>> out;
+        const size_t block = 4000 * 40;  // 40 ms per push
+        int launches = 0;
+        for (size_t pos = 0, b = 0; pos + block <= n; pos += block, b++)
+            {
+                EXPECT(gc_stream_push(ring, x.data() + pos, block, nullptr) == GC_OK, "group: push (%s)", gc_last_error());
+                // hand-overs as acquisitions would deliver them; the code delay is relative to the acquisition stamp (a multiple of a code period here)
+                if (b == 0)
+                    {
+                        EXPECT(group.start_tracking(0, acq_of(0, 0), 0) == GC_OK, "group: start 0 (%s)", gc_last_error());
+                        EXPECT(group.start_tracking(4, acq_of(1, 0), 0) == GC_OK, "group: start 4 (%s)", gc_last_error());
+                    }
+                if (b == 3)
+                    {
+                        EXPECT(group.start_tracking(2, acq_of(2, pos), pos) == GC_OK, "group: start 2 (%s)", gc_last_error());
+                        Gnss_Synchro ghost = acq_of(3, pos);
+                        ghost.PRN = 30;  // not in the stream
+                        EXPECT(group.start_tracking(5, ghost, pos) == GC_OK, "group: start 5 (%s)", gc_last_error());
+                    }
+                if (b == 6) EXPECT(group.start_tracking(1, acq_of(3, pos), pos) == GC_OK, "group: start 1 (%s)", gc_last_error());
+                const int produced = group.run(out);
+                EXPECT(produced >= 0, "group: run failed, status %d (%s)", group.last_status(), gc_last_error());
+                if (produced < 0) break;
+                launches++;
+            }
+        const int slot_of[4] = {0, 4, 2, 1};
+        const size_t expect_min[4] = {1470, 1470, 1350, 1230};
+        for (int k = 0; k < 4; k++)
+            {
+                const auto& o = out[slot_of[k]];
+                EXPECT(o.size() >= expect_min[k] && group.active(slot_of[k]), "group: PRN %d produced %zu items", prns[k], o.size());
+                if (o.empty()) continue;
+                double mean = 0.0;
+                int cnt = 0;
+                for (size_t i = o.size() > 200 ? o.size() - 200 : 0; i < o.size(); i++, cnt++) mean += o[i].Carrier_Doppler_hz;
+                mean /= std::max(1, cnt);
+                EXPECT(std::fabs(mean - dopplers[k]) < 3.0 && o.back().PRN == static_cast<uint32_t>(prns[k]), "group: PRN %d mean Doppler %.2f Hz, truth %.2f", prns[k], mean,
+                    dopplers[k]);
+                EXPECT(o.back().CN0_dB_hz > 40.0, "group: PRN %d C/N0 %.1f", prns[k], o.back().CN0_dB_hz);
+                // consecutive periods, one Gnss_Synchro each
+                bool monotone = true;
+                for (size_t i = 1; i < o.size(); i++) monotone = monotone && o[i].Tracking_sample_counter > o[i - 1].Tracking_sample_counter && o[i].Tracking_sample_counter - o[i - 1].Tracking_sample_counter < 4003;
+                EXPECT(monotone, "group: PRN %d sample counters are not consecutive code periods", prns[k]);
+            }
+        EXPECT(!group.active(5) && group.events(5).size() == 1 && group.events(5)[0] == 3, "group: the ghost satellite's slot did not report loss of lock (%zu events)",
+            group.events(5).size());
+        EXPECT(!group.active(3) && out[3].empty(), "group: the unused slot produced %zu items", out[3].size());
+        std::printf("tracking group: 4 satellites + 1 ghost on 6 slots, %d launches for %.0f ms of signal: %zu / %zu / %zu / %zu Gnss_Synchro, ghost lost lock after %zu\n", launches,
+            n / fs * 1e3, out[0].size(), out[4].size(), out[2].size(), out[1].size(), out[5].size());
+    }
+    gc_stream_destroy(ring);
+    gc_ctx_destroy(ctx);
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -894,6 +1001,7 @@ int main()
     test_glonass_fdma_tracking();
     test_gps_c_aid_tracking();
     test_device_loop_block();
+    test_tracking_group();
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

@@ -15,6 +15,7 @@
 // data-component prompt correlator of pilot tracking (:899-910) and the high-dynamics rate smoothers (:1016-1064).
 #include "gc_internal.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include "gc_stream.h"
 #include "trk_device.hpp"
@@ -630,7 +631,16 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
         for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += THREADS) dst[i] = src[i];
     }
     __syncthreads();
-    if (s.n_taps != NTAPS) return;
+    if (s.n_taps != NTAPS)
+        {
+            // a channel that has not been started (or was stopped): standby records, nothing else
+            for (int e = 0; e < n_epochs; e++)
+                {
+                    unsigned* w = reinterpret_cast<unsigned*>(&recs[(size_t)ch * n_epochs + e]);
+                    for (unsigned i = tid; i < sizeof(gc_loop_record) / 4; i += THREADS) w[i] = 0u;
+                }
+            return;
+        }
     // samples available to this launch: the channel's buffer length, or (ring input) the stream's head
     const unsigned long long limit = limits ? limits[ch] : s.chan.n_iq;
 
@@ -741,6 +751,7 @@ struct gc_trk_loop
     std::vector<gc_stream*> streams;          // per channel, or NULL
     std::vector<unsigned long long> pos_host; // last known stream position of the channel (from the records)
     std::vector<char> pos_known;
+    std::vector<char> idle;                   // the channel's last record said state 0 (standby after loss of lock)
     unsigned long long* d_limits = nullptr;
     unsigned long long* h_limits = nullptr;   // pinned
 };
@@ -782,6 +793,7 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
     l->streams.assign(n_channels, nullptr);
     l->pos_host.assign(n_channels, 0);
     l->pos_known.assign(n_channels, 0);
+    l->idle.assign(n_channels, 0);
     if (hipMalloc(&l->d_limits, sizeof(unsigned long long) * n_channels) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&l->h_limits), sizeof(unsigned long long) * n_channels, hipHostMallocDefault) != hipSuccess)
         {
@@ -1004,6 +1016,7 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
     h.pos = l->streams[ch] ? conf->sample_counter : 0;
     l->pos_host[ch] = h.pos;
     l->pos_known[ch] = 1;
+    l->idle[ch] = 0;
     GC_HIP(hipMemcpy(l->d_chans + ch, &h, sizeof h, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(trk_loop_start_kernel, dim3(1), dim3(64), 0, st, l->d_chans, ch);
     GC_HIP(hipGetLastError());
@@ -1012,10 +1025,33 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
     return GC_OK;
 }
 
+}  // extern "C"
+
+extern "C" gc_status gc_trk_loop_stop(gc_trk_loop* l, int ch)
+{
+    GC_REQUIRE(l, "gc_trk_loop_stop: NULL handle");
+    GC_REQUIRE(ch >= 0 && ch < l->n_channels, "gc_trk_loop_stop: channel %d out of range", ch);
+    gc_device_guard g(l->ctx->device);
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    if (!l->started[ch]) return GC_OK;
+    GC_HIP(hipStreamSynchronize(l->ctx->stream));
+    // n_taps = 0 marks the slot as standby for the kernel; the rest of the state is rewritten by the next start
+    int zero = 0;
+    GC_HIP(hipMemcpy(reinterpret_cast<char*>(l->d_chans + ch) + offsetof(LoopChan, n_taps), &zero, sizeof zero, hipMemcpyHostToDevice));
+    l->started[ch] = 0;
+    return GC_OK;
+}
+
+extern "C" {
+
 static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, hipStream_t st, bool positions_known)
 {
-    for (int i = 0; i < l->n_channels; i++)
-        if (!l->started[i]) return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: channel %d has not been started (gc_trk_loop_start)", i);
+    {
+        // channels that were never started (or were stopped) sit in standby: all-zero records, state 0
+        bool any = false;
+        for (int i = 0; i < l->n_channels; i++) any |= l->started[i] != 0;
+        if (!any) return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: no channel has been started (gc_trk_loop_start)");
+    }
     // ring inputs: this launch may use what has been pushed so far, and must not be overtaken by later pushes
     std::vector<gc_stream*> rings;
     std::vector<uint64_t> floors;
@@ -1026,6 +1062,12 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
             l->h_limits[i] = l->n_iq[i];
             if (!r) continue;
             any_ring = true;
+            if (!l->started[i] || l->idle[i])
+                {
+                    // standby (never started, stopped, or lost lock): reads nothing, holds nothing back in the ring
+                    l->h_limits[i] = 0;
+                    continue;
+                }
             uint64_t oldest = 0, head = 0;
             gc_stream_info(r, &oldest, &head, nullptr);
             l->h_limits[i] = head;
@@ -1161,10 +1203,12 @@ gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_rec
     GC_HIP(hipStreamSynchronize(st));
     // ring channels: Tracking_sample_counter of the last record IS the absolute position (it started at sample_counter)
     for (int i = 0; i < l->n_channels; i++)
-        if (l->streams[i])
+        if (l->streams[i] && l->started[i])
             {
-                l->pos_host[i] = host_records[(size_t)i * n_epochs + (n_epochs - 1)].sample_counter;
+                const gc_loop_record& last = host_records[(size_t)i * n_epochs + (n_epochs - 1)];
+                l->pos_host[i] = last.sample_counter;
                 l->pos_known[i] = 1;
+                l->idle[i] = last.state == 0;  // loss of lock: the channel waits for the next gc_trk_loop_start
             }
     return GC_OK;
 }

@@ -204,6 +204,7 @@ API = {
     "gc_trk_loop_set_sync": (C.c_int, [_vp, C.c_int, C.POINTER(LoopSyncConf), _fp, C.c_int]),
     "gc_loop_sync_for_signal": (C.c_int, [C.c_char, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(LoopSyncConf)]),
     "gc_trk_loop_start": (C.c_int, [_vp, C.c_int, C.POINTER(LoopConf), _fp, C.c_int]),
+    "gc_trk_loop_stop": (C.c_int, [_vp, C.c_int]),
     "gc_trk_loop_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "gc_trk_loop_run": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_gps_l1_ca_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
@@ -737,6 +738,9 @@ class TrackingLoop:
     def start(self, ch, conf, code):
         code = np.ascontiguousarray(code, np.float32)
         _check(load_library().gc_trk_loop_start(self._h, ch, C.byref(conf), _f32p(code), code.size))
+
+    def stop(self, ch):
+        _check(load_library().gc_trk_loop_stop(self._h, ch))
 
     def run(self, n_epochs):
         """Returns a structured array [n_channels, n_epochs] of LOOP_RECORD_DTYPE."""

@@ -360,6 +360,9 @@ gc_status gc_trk_loop_set_sync(gc_trk_loop* l, int ch, const gc_loop_sync_conf* 
 /* dll_pll_veml_tracking::start_tracking (:549-747): uploads the replica (code_length_chips *
  * code_samples_per_chip floats), sets the taps from the spacings and initialises the loop. */
 gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, const float* code, int code_length);
+/* Puts channel `ch` back in standby (all-zero records, state 0) until the next gc_trk_loop_start; channels that were never
+ * started are in the same state, so an engine can be sized for the receiver's channel count and filled as acquisitions succeed. */
+gc_status gc_trk_loop_stop(gc_trk_loop* l, int ch);
 /* n_epochs code periods of every channel in ONE launch.  dev_records: n_channels*n_epochs records,
  * channel-major.  The loop state persists on the device between calls. */
 gc_status gc_trk_loop_run_dev(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, void* stream);

@@ -290,3 +290,40 @@ def test_closed_loop_high_dynamics(gctx, oracle):
     with pytest.raises(gnsscorr.GnsscorrError, match="high_dyn mode"):
         loop.start(1, _conf(gnsscorr, **dict(conf, high_dyn_smoother_length=0)), code)
     loop.close()
+
+
+def test_closed_loop_standby_slots_and_stop(gctx, oracle):
+    """An engine sized for the receiver's channel count: slots that were never started, were stopped, or lost lock produce all-zero
+    standby records and do not disturb the running ones (gc_trk_loop_stop)."""
+    import gnsscorr
+    import torch
+    fs, n_ep = 4e6, 40
+    code, x = _signal(oracle, 5, fs, 4000 * (n_ep + 3), 101, 1680.0, 1234.0)
+    conf = _conf(gnsscorr, **dict(GPS, acq_delay_samples=1234.0, acq_doppler_hz=1690.0, acq_samplestamp_samples=0, sample_counter=0))
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    solo = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    solo.set_input_dev(0, d.data_ptr(), x.size)
+    solo.start(0, conf, code)
+    want = solo.run(n_ep)[0]
+    solo.close()
+    loop = gnsscorr.TrackingLoop(gctx, 3, 1023)
+    for ch in range(3):
+        loop.set_input_dev(ch, d.data_ptr(), x.size)
+    with pytest.raises(gnsscorr.GnsscorrError, match="no channel has been started"):
+        loop.run(1)
+    loop.start(1, conf, code)
+    rec = loop.run(n_ep // 2)
+    assert np.all(rec[0].view(np.uint8) == 0) and np.all(rec[2].view(np.uint8) == 0)
+    loop.start(2, conf, code)  # a later hand-over into a free slot
+    rec2 = loop.run(n_ep - n_ep // 2)
+    got = np.concatenate([rec[1], rec2[1]])
+    for f in ("corr", "sample_counter", "carrier_doppler_hz", "state", "valid"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(rec2[2]["corr"], want["corr"][:n_ep - n_ep // 2])  # slot 2 started from the beginning of its block
+    loop.stop(1)
+    rec3 = loop.run(2)
+    assert np.all(rec3[1].view(np.uint8) == 0) and np.all(rec3[0].view(np.uint8) == 0) and np.all(rec3[2]["valid"] == 1)
+    loop.stop(2)
+    with pytest.raises(gnsscorr.GnsscorrError, match="no channel has been started"):
+        loop.run(1)
+    loop.close()

@@ -28,3 +28,15 @@ def test_c_example_runs(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "receiver flow ok" in p.stdout and p.stdout.count("<- acquired") == 4 and p.stdout.count("locked") >= 4
     assert "NOT LOCKED" not in p.stdout
+
+
+def test_python_receiver_front_end_example():
+    """examples/receiver_bench.py: ring push -> 32-PRN PCPS search -> hand-over into free slots of one closed-loop engine ->
+    tracking, at 4 Msps for half a second: every satellite of the stream found (no false alarm) and tracked to within 5 Hz."""
+    import json
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "receiver_bench.py"), "--fs", "4000000", "--seconds", "0.5"], capture_output=True,
+        text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["all_found_and_tracked"] and d["detected"] == d["satellites_in_stream"] and len(d["detected"]) == 8

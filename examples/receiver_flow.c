@@ -57,6 +57,11 @@ int main(void)
     float code[N_PRESENT][1023];
     int s, ch;
     size_t i;
+    if (GC_ABI_CHECK() != GC_OK)
+        {
+            printf("%s\n", gc_last_error()); /* this program was compiled against another gnsscorr.h than the library */
+            return 2;
+        }
     if (gc_device_count() == 0)
         {
             printf("no GPU: libgnsscorr has no CPU fallback\n");

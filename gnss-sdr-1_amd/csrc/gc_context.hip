@@ -39,7 +39,24 @@ extern "C" {
 
 const char* gc_last_error(void) { return g_err; }
 
-const char* gc_version(void) { return "gnsscorr 0.1 (gfx950)"; }
+const char* gc_version(void) { return "gnsscorr 0.2 (gfx950)"; }
+
+gc_status gc_abi_check(size_t sizeof_epoch_params, size_t sizeof_loop_conf, size_t sizeof_loop_record, size_t sizeof_loop_sync_conf, size_t sizeof_acq_conf,
+    size_t sizeof_acq_result)
+{
+    const struct
+    {
+        const char* name;
+        size_t theirs, ours;
+    } t[] = {{"gc_epoch_params", sizeof_epoch_params, sizeof(gc_epoch_params)}, {"gc_loop_conf", sizeof_loop_conf, sizeof(gc_loop_conf)},
+        {"gc_loop_record", sizeof_loop_record, sizeof(gc_loop_record)}, {"gc_loop_sync_conf", sizeof_loop_sync_conf, sizeof(gc_loop_sync_conf)},
+        {"gc_acq_conf", sizeof_acq_conf, sizeof(gc_acq_conf)}, {"gc_acq_result", sizeof_acq_result, sizeof(gc_acq_result)}};
+    for (const auto& e : t)
+        if (e.theirs != e.ours)
+            return gc_fail(GC_ERR_INVALID, "gc_abi_check: %s is %zu bytes in the caller's binding, %zu in this library (%s): header and library differ", e.name,
+                e.theirs, e.ours, gc_version());
+    return GC_OK;
+}
 
 int gc_device_count(void)
 {

@@ -154,6 +154,7 @@ _i16p = C.POINTER(C.c_int16)
 API = {
     "gc_last_error": (C.c_char_p, []),
     "gc_version": (C.c_char_p, []),
+    "gc_abi_check": (C.c_int, [C.c_size_t] * 6),
     "gc_device_count": (C.c_int, []),
     "gc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "gc_ctx_destroy": (C.c_int, [_vp]),
@@ -264,6 +265,10 @@ def load_library():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        # the ctypes mirrors above against the library that was actually loaded
+        st = lib.gc_abi_check(C.sizeof(EpochParams), C.sizeof(LoopConf), LOOP_RECORD_DTYPE.itemsize, C.sizeof(LoopSyncConf), C.sizeof(AcqConf), C.sizeof(AcqResult))
+        if st != 0:
+            raise GnsscorrError(st, lib.gc_last_error().decode() + " -- rebuild with __graft_entry__.build()")
         _lib = lib
     return _lib
 

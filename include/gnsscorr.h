@@ -55,6 +55,11 @@ enum
 const char* gc_last_error(void);
 /* Library version string. */
 const char* gc_version(void);
+/* Layout check between a binding and the loaded library: the sizes of the structures that cross the ABI, as the CALLER's
+ * header (or ctypes / cgo / JNI mirror) sees them.  GC_OK when they all match the library's.  C and C++ callers use
+ * GC_ABI_CHECK() after including this header (the macro is at its end). */
+gc_status gc_abi_check(size_t sizeof_epoch_params, size_t sizeof_loop_conf, size_t sizeof_loop_record, size_t sizeof_loop_sync_conf,
+    size_t sizeof_acq_conf, size_t sizeof_acq_result);
 /* Number of visible HIP devices (0 when none; never fails). */
 int gc_device_count(void);
 
@@ -503,6 +508,9 @@ gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* str
 gc_status gc_acq_dwell_stream(gc_acq* a, gc_stream* s, uint64_t first_index, gc_acq_result* host_results);
 /* Copies satellite `sat`'s magnitude grid (num_doppler_bins * fft_size floats) to host. */
 gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid);
+
+#define GC_ABI_CHECK() \
+    gc_abi_check(sizeof(gc_epoch_params), sizeof(gc_loop_conf), sizeof(gc_loop_record), sizeof(gc_loop_sync_conf), sizeof(gc_acq_conf), sizeof(gc_acq_result))
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,13 @@ def test_argument_validation_without_gpu():
     assert lib.gc_trk_batch_set_slices(None, 1) == gnsscorr.GC_ERR_INVALID
     assert lib.gc_acq_fft_size(None, None, None, None) == gnsscorr.GC_ERR_INVALID
     assert lib.gc_version().startswith(b"gnsscorr")
+    # layout check of a binding against the library: the real sizes pass, a stale mirror is named
+    sizes = [C.sizeof(gnsscorr.EpochParams), C.sizeof(gnsscorr.LoopConf), gnsscorr.LOOP_RECORD_DTYPE.itemsize, C.sizeof(gnsscorr.LoopSyncConf),
+        C.sizeof(gnsscorr.AcqConf), C.sizeof(gnsscorr.AcqResult)]
+    assert lib.gc_abi_check(*sizes) == 0
+    stale = list(sizes)
+    stale[2] = 112  # the record of an older header
+    assert lib.gc_abi_check(*stale) != 0 and b"gc_loop_record is 112 bytes" in lib.gc_last_error()
 
 
 def test_product_does_not_import_the_oracle():

@@ -8,7 +8,7 @@
  *
  * Same configuration (Dll_Pll_Conf), same signals and the same per-period results as hip_dll_pll_veml_tracking /
  * dll_pll_veml_tracking (src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.cc); the state machine itself lives in
- * trk_closed_loop.hip.  high_dyn together with track_pilot is the one combination the device loop does not offer.
+ * trk_closed_loop.hip.
  */
 #ifndef GNSSCORR_HIP_DLL_PLL_VEML_TRACKING_DEV_H_
 #define GNSSCORR_HIP_DLL_PLL_VEML_TRACKING_DEV_H_

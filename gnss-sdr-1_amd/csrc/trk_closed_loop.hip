@@ -976,7 +976,7 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
         }
     GC_REQUIRE(l->pilot == y.track_pilot, "gc_trk_loop_start: all channels of one loop engine share the pilot mode (track_pilot = %d)", l->pilot);
     GC_REQUIRE(l->high_dyn == hd, "gc_trk_loop_start: all channels of one loop engine share the high_dyn mode (%d)", l->high_dyn);
-    GC_REQUIRE(!(hd && y.track_pilot), "gc_trk_loop_start: high_dyn together with track_pilot is not available in the device loop");
+
     hipStream_t st = l->ctx->stream;
     GC_HIP(hipStreamSynchronize(st));
     GC_HIP(hipMemcpy(l->d_codes + (size_t)ch * l->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
@@ -1128,9 +1128,23 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
     if (l->high_dyn)
         {
             // high-dynamics kernels: 256 threads per channel (the per-sample exact rotator keeps a workgroup busy)
-#define LAUNCH_LOOP_HD(NT, FM)                                                                                                                   \
-    hipLaunchKernelGGL((trk_closed_loop_kernel<NT, 256, FM, false, true>), dim3(l->n_channels), dim3(256), lds_bytes_hd, st, l->d_chans, dev_records, \
-        n_epochs, lds_table_floats, limits)
+#define LAUNCH_LOOP_HD_D(NT, FM, DA)                                                                                                              \
+    do                                                                                                                                        \
+        {                                                                                                                                     \
+            if (lds_bytes_hd > 48 * 1024)                                                                                                     \
+                GC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, 256, FM, DA, true>),                     \
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_hd));                                                          \
+            hipLaunchKernelGGL((trk_closed_loop_kernel<NT, 256, FM, DA, true>), dim3(l->n_channels), dim3(256), lds_bytes_hd, st, l->d_chans,  \
+                dev_records, n_epochs, lds_table_floats, limits);                                                                             \
+        }                                                                                                                                     \
+    while (0)
+#define LAUNCH_LOOP_HD(NT, FM)                     \
+    do                                             \
+        {                                          \
+            if (pilot) LAUNCH_LOOP_HD_D(NT, FM, true); \
+            else LAUNCH_LOOP_HD_D(NT, FM, false);  \
+        }                                          \
+    while (0)
             const size_t lds_bytes_hd = (size_t)(trk_hdr_floats(256) + lds_table_floats) * sizeof(float);
             if (l->n_taps == 5)
                 {
@@ -1145,6 +1159,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
                     else LAUNCH_LOOP_HD(3, GC_IQ_F32);
                 }
 #undef LAUNCH_LOOP_HD
+#undef LAUNCH_LOOP_HD_D
         }
     else if (l->n_taps == 5)
         {

@@ -170,7 +170,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
     float (&accr)[NTAPS + (DATA ? 1 : 0)], float (&acci)[NTAPS + (DATA ? 1 : 0)], const float* __restrict__ table2 = nullptr)
 {
-    static_assert(!DATA || (!HDR && !HDC && !CC && !SC16), "the data-component correlator exists in the plain float mode only");
+    static_assert(!DATA || (!CC && !SC16), "the data-component correlator exists for real float replicas only");
     constexpr int CHUNK = 2 * THREADS;
     constexpr int PT = NTAPS / 2;  // prompt tap of E/P/L and VE/E/P/L/VL
     const int tid = threadIdx.x;
@@ -328,6 +328,19 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
                         const int i1 = chip_index_hd(step, rate, (unsigned)m1, shifts[0], rem);
                         mac(y0r, y0i, i0, accr[t], acci[t]);
                         mac(y1r, y1i, i1, accr[t], acci[t]);
+                    }
+                if constexpr (DATA)
+                    {
+                        // the data correlator is its own one-tap object: ITS first tap is the prompt shift, evaluated with the
+                        // high-dynamics formula at the sample itself (no tap delay)
+                        const int j0 = chip_index_hd(step, rate, (unsigned)n0, shifts[PT], rem);
+                        const int j1 = chip_index_hd(step, rate, (unsigned)n1, shifts[PT], rem);
+                        const float d0 = WINDOWED ? tl2[j0] : table2[posmod(j0, L)];
+                        const float d1 = WINDOWED ? tl2[j1] : table2[posmod(j1, L)];
+                        accr[NTAPS] = fmaf(y0r, d0, accr[NTAPS]);
+                        acci[NTAPS] = fmaf(y0i, d0, acci[NTAPS]);
+                        accr[NTAPS] = fmaf(y1r, d1, accr[NTAPS]);
+                        acci[NTAPS] = fmaf(y1i, d1, acci[NTAPS]);
                     }
             }
         else
@@ -558,6 +571,12 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
         {
             lo = chip_index_hd(step, rate, (unsigned)n_lo, shifts[0], rem);
             hi = chip_index_hd(step, rate, (unsigned)n_hi, shifts[0], rem);
+            if (DATA)
+                {
+                    // the data tap walks the same samples with the prompt shift instead of the first tap's
+                    lo = min(lo, chip_index_hd(step, rate, (unsigned)n_lo, shifts[NTAPS / 2], rem));
+                    hi = max(hi, chip_index_hd(step, rate, (unsigned)n_hi, shifts[NTAPS / 2], rem));
+                }
             // float ops are monotone, so the index is monotone in n when both terms are
             monotone = (step > 0.0f) && (rate >= 0.0f) && ((unsigned long long)n_hi * n_hi < 0xffffffffull);
         }

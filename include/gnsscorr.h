@@ -292,7 +292,7 @@ typedef struct
     float early_late_space_chips, very_early_late_space_chips;
     uint32_t high_dyn_smoother_length; /* 0: Dll_Pll_Conf::high_dyn false; n > 0: high_dyn with smoother_length n (<= 16): the
                                         * high-dynamics resampler / rotator kernels and the carrier / code rate smoothers of
-                                        * update_tracking_vars (:1016-1033, :1047-1064); not combined with track_pilot here */
+                                        * update_tracking_vars (:1016-1033, :1047-1064) */
 } gc_loop_conf;
 
 /* One code period of one channel: the correlator outputs plus what the block writes to Gnss_Synchro

@@ -294,10 +294,11 @@ def test_randomised_level1_call_sequences(gctx, oracle):
         mc.close()
 
 
-def _random_loop_case(rng, veml=None, pilot=None):
+def _random_loop_case(rng, veml=None, pilot=None, high_dyn=None):
     """A random signal + loop configuration for the closed-loop state machine (synchronisation, extension, pilot)."""
     from test_loop_sync_gpu import _stream
     force_pilot = pilot
+    hd = high_dyn if high_dyn is not None else (int(rng.integers(2, 11)) if rng.uniform() < 0.3 else 0)  # Dll_Pll_Conf::high_dyn + smoother_length
     veml = bool(rng.integers(0, 2)) if veml is None else veml
     spc = 2 if veml else 1
     L = int(rng.integers(150, 1200)) * spc            # code samples per period
@@ -340,14 +341,28 @@ def _random_loop_case(rng, veml=None, pilot=None):
         dll_filter_order=int(rng.integers(1, 4)), enable_fll_pull_in=0, enable_fll_steady_state=int(rng.integers(0, 2)), cn0_samples=int(rng.integers(5, 21)),
         cn0_min=25, max_lock_fail=50, pll_bw_hz=float(rng.uniform(25, 45)), dll_bw_hz=float(rng.uniform(1, 3)), fll_bw_hz=10.0,
         early_late_space_chips=float(rng.uniform(0.2, 0.5)), very_early_late_space_chips=float(rng.uniform(0.55, 0.7)), acq_samplestamp_samples=0,
-        sample_counter=0, acq_delay_samples=delay, acq_doppler_hz=doppler + float(rng.uniform(-3, 3)))
+        sample_counter=0, acq_delay_samples=delay, acq_doppler_hz=doppler + float(rng.uniform(-3, 3)),
+        high_dyn_smoother_length=hd)
     return x, code, (data_code if pilot else None), conf, y, n_ep, (5 if veml else 3)
+
+
+def _agreeing_prefix(rec, ref):
+    """Number of leading periods whose block boundaries agree.  The block length is floor(T_prn + remainder) in double precision
+    (dll_pll_veml_tracking.cc:1009): when that sum falls within ~1e-9 of a whole sample, the device's libm and numpy may round it
+    to different sides -- one sample, once in tens of thousands of periods -- and the two runs are different (equally valid) runs
+    from there on."""
+    for k in range(min(len(rec), len(ref))):
+        if int(rec[k]["sample_counter"]) != ref[k]["sample_counter"]:
+            assert abs(int(rec[k]["sample_counter"]) - ref[k]["sample_counter"]) == 1, (k, int(rec[k]["sample_counter"]), ref[k]["sample_counter"])
+            return k
+    return min(len(rec), len(ref))
 
 
 def test_randomised_loop_state_machine(gctx, oracle):
     """Closed-loop engine vs the Python restatement over random synchronisation set-ups: random replicas and code lengths,
     3 / 5 taps, secondary codes of 4..30 symbols with and without a pilot + data component, preambles in both polarities,
-    1..5 symbol integrations, loop-filter orders, FLL assistance.  State sequence and block boundaries must be identical."""
+    1..5 symbol integrations, loop-filter orders, FLL assistance, the high-dynamics kernels and rate smoothers.  State sequence and block
+    boundaries must be identical."""
     import gnsscorr
     import torch
     from closed_loop_ref import run as ref_run
@@ -355,6 +370,7 @@ def test_randomised_loop_state_machine(gctx, oracle):
     seed = int(os.environ.get("GNSSCORR_FUZZ_SEED", "20240611"))
     rng = np.random.Generator(np.random.PCG64(seed + 5))
     reached = {2: 0, 3: 0, 4: 0}
+    forks = compared = 0
     for case in range(int(os.environ.get("GNSSCORR_FUZZ_LOOP_CASES", "24"))):
         x, code, data_code, conf, y, n_ep, n_taps = _random_loop_case(rng)
         ref = ref_run(oracle, x, code, conf, n_ep, sync=y, data_code=data_code)
@@ -367,8 +383,11 @@ def test_randomised_loop_state_machine(gctx, oracle):
         k = int(rng.integers(1, n_ep))
         rec = np.concatenate([loop.run(k)[0], loop.run(n_ep - k)[0]])
         loop.close()
+        keep_n = _agreeing_prefix(rec, ref)
+        forks += keep_n < len(ref)
+        compared += keep_n
         try:
-            _compare(rec[:len(ref)], ref, n_taps, tol=5e-3, abs_tol=2.2 * float(np.abs(x).max()))
+            _compare(rec[:keep_n], ref[:keep_n], n_taps, tol=5e-3, abs_tol=4.0 * float(np.abs(x).max()))  # up to two samples across a chip edge
         except AssertionError as e:
             raise AssertionError("case %d (seed %d): %s\nsync %r" % (case, seed, e, y)) from e
         reached[int(rec["state"][len(ref) - 1])] = reached.get(int(rec["state"][len(ref) - 1]), 0) + 1
@@ -376,7 +395,8 @@ def test_randomised_loop_state_machine(gctx, oracle):
     # several channels of one engine, each with its own signal, rates, synchronisation data and block length
     for group in range(int(os.environ.get("GNSSCORR_FUZZ_LOOP_GROUPS", "6"))):
         veml, pilot = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-        cases = [_random_loop_case(rng, veml=veml, pilot=pilot) for _ in range(int(rng.integers(2, 6)))]
+        hd = int(rng.integers(2, 11)) if rng.uniform() < 0.3 else 0  # one engine, one high_dyn mode (the smoother length may differ)
+        cases = [_random_loop_case(rng, veml=veml, pilot=pilot, high_dyn=(int(rng.integers(2, 11)) if hd else 0)) for _ in range(int(rng.integers(2, 6)))]
         refs = [ref_run(oracle, x, code, conf, n_ep, sync=y, data_code=dc) for x, code, dc, conf, y, n_ep, _ in cases]
         loop = gnsscorr.TrackingLoop(gctx, len(cases), max(c[1].size for c in cases))
         keep = []
@@ -391,9 +411,13 @@ def test_randomised_loop_state_machine(gctx, oracle):
         rec = np.concatenate([loop.run(k), loop.run(n_max - k)], axis=1)
         loop.close()
         for ch, (x, code, dc, conf, y, n_ep, n_taps) in enumerate(cases):
+            keep_n = _agreeing_prefix(rec[ch], refs[ch])
+            forks += keep_n < len(refs[ch])
+            compared += keep_n
             try:
-                _compare(rec[ch, :len(refs[ch])], refs[ch], n_taps, tol=5e-3, abs_tol=2.2 * float(np.abs(x).max()))
+                _compare(rec[ch, :keep_n], refs[ch][:keep_n], n_taps, tol=5e-3, abs_tol=4.0 * float(np.abs(x).max()))  # up to two samples across a chip edge
             except AssertionError as e:
                 raise AssertionError("group %d channel %d (seed %d): %s\nsync %r" % (group, ch, seed, e, y)) from e
             # past the end of its input a channel produces invalid records and keeps its state
             assert np.all(rec[ch, len(refs[ch]) + 1:]["valid"] == 0)
+    assert forks <= 1 + compared // 10000, (forks, compared)  # one-sample forks of the block length are rare events

@@ -304,3 +304,36 @@ def test_gps_l5_pilot_in_quadrature_on_the_device_loop(gctx, oracle):
     want = dsym[(np.arange(n_ep)[tail] + 2) % dsym.size]
     assert abs(np.sum(got * want)) == got.size
     assert np.median(np.abs(rec["prompt_data"][tail, 1])) > 2 * np.median(np.abs(rec["prompt_data"][tail, 0]))
+
+
+def test_pilot_tracking_with_high_dynamics_kernels(gctx, oracle):
+    """track_pilot together with high_dyn: the data correlator is its own one-tap object, so with the high-dynamics resampler its
+    chip index is the prompt shift evaluated at the sample itself, not the main correlator's delayed first tap."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    z = np.load(os.path.join(G, "galileo_e1_codes.npz"))
+    e1b, e1c = oracle.galileo_e1_sinboc11(z["e1b"][22]), oracle.galileo_e1_sinboc11(z["e1c"][22])
+    fs, n_ep = 4e6, 60
+    rng = np.random.Generator(np.random.PCG64(15))
+    data = rng.integers(0, 2, 400) * 2 - 1
+    sec = np.roll(np.array([1.0 if c == "0" else -1.0 for c in E1C_SECONDARY]), 4)
+    doppler, delay = -3010.0, 9000.0
+    x = _stream([(e1b, data, 1.0), (e1c, sec, 1.0)], fs, 16000 * (n_ep + 3), doppler, delay, 48.0, 78, 2.046e6)
+    conf = dict(GAL, acq_delay_samples=delay, acq_doppler_hz=doppler + 1.0, pll_bw_hz=25.0, high_dyn_smoother_length=6)
+    y = dict(extend_correlation_symbols=2, track_pilot=True, symbols_per_bit=1, secondary_code=E1C_SECONDARY, pll_bw_narrow_hz=10.0,
+        dll_bw_narrow_hz=0.5, early_late_space_narrow_chips=0.15, very_early_late_space_narrow_chips=0.6)
+    ref = ref_run(oracle, x, e1c, conf, n_ep, sync=y, data_code=e1b)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 8184)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.set_sync(0, _sync(gnsscorr, y), e1b)
+    loop.start(0, _conf(gnsscorr, **conf), e1c)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    _compare(rec, ref, 5, abs_tol=2.2 * float(np.abs(x).max()))
+    first = int(np.argmax(rec["state"] != 2))
+    assert first == 4 + 25 - 1 - 2 and set(rec["state"][first:].tolist()) == {3, 4}
+    got = np.sign(rec["prompt_data"][first + 6:, 0])
+    want = data[(np.arange(first + 6, n_ep) + 2) % data.size]
+    assert abs(np.sum(got * want)) == got.size

@@ -128,6 +128,21 @@ gc_status gc_stream_push_pinned(gc_stream* s, const void* pinned_host_iq, uint64
     return stream_push(s, pinned_host_iq, n_samples, first_index, true);
 }
 
+gc_status gc_stream_broadcast_pinned(gc_stream* const* rings, int n_rings, const void* pinned_host_iq, uint64_t n_samples)
+{
+    GC_REQUIRE(rings && n_rings > 0 && pinned_host_iq, "gc_stream_broadcast_pinned: bad argument");
+    // every ring has its own copy stream (and, on another GPU, its own DMA engines and link): the copies are enqueued back to
+    // back and run concurrently; nothing is exchanged between the GPUs
+    for (int i = 0; i < n_rings; i++)
+        {
+            GC_REQUIRE(rings[i], "gc_stream_broadcast_pinned: ring %d is NULL", i);
+            GC_REQUIRE(rings[i]->iq_format == rings[0]->iq_format, "gc_stream_broadcast_pinned: ring %d has another sample format", i);
+            gc_status st = stream_push(rings[i], pinned_host_iq, n_samples, nullptr, true);
+            if (st != GC_OK) return st;
+        }
+    return GC_OK;
+}
+
 }  // extern "C"
 
 static gc_status stream_push(gc_stream* s, const void* host_iq, uint64_t n_samples, uint64_t* first_index, bool pinned)

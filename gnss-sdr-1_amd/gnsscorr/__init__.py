@@ -177,6 +177,7 @@ API = {
     "gc_stream_destroy": (C.c_int, [_vp]),
     "gc_stream_push": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gc_stream_push_pinned": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "gc_stream_broadcast_pinned": (C.c_int, [C.POINTER(_vp), C.c_int, _vp, C.c_uint64]),
     "gc_stream_info": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gc_stream_synchronize": (C.c_int, [_vp]),
     "gc_trk_loop_set_input_format": (C.c_int, [_vp, C.c_int]),
@@ -620,6 +621,12 @@ class HipMulticorrelator16sc(HipMulticorrelatorRealCodes):
         _check(load_library().gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(self._h, rem_carrier_phase_in_rad,
             phase_step_rad, rem_code_phase_chips, code_phase_step_chips, int(signal_length_samples)))
         return True
+
+
+def stream_broadcast_pinned(streams, host_ptr, n_samples):
+    """gc_stream_broadcast_pinned: one page-locked block into the ring of every GPU."""
+    arr = (_vp * len(streams))(*[s._h for s in streams])
+    _check(load_library().gc_stream_broadcast_pinned(arr, len(streams), _vp(host_ptr), int(n_samples)))
 
 
 class TrackingBatch:

@@ -161,6 +161,10 @@ gc_status gc_stream_push(gc_stream* s, const void* host_iq, uint64_t n_samples, 
 /* Same for a PAGE-LOCKED host buffer (hipHostMalloc / hipHostRegister, e.g. a pinned torch tensor): the DMA
  * reads it directly, without the staging copy, so it must stay untouched until gc_stream_synchronize(). */
 gc_status gc_stream_push_pinned(gc_stream* s, const void* pinned_host_iq, uint64_t n_samples, uint64_t* first_index);
+/* The same page-locked block into several rings -- the RF stream's copy on each GPU of a node (channels are
+ * sharded over the GPUs, every GPU needs the whole stream, no collective): G independent H2D copies enqueued back to back, each
+ * on its ring's own copy stream.  The rings share the sample format; the block stays untouched until every ring is synchronised. */
+gc_status gc_stream_broadcast_pinned(gc_stream* const* rings, int n_rings, const void* pinned_host_iq, uint64_t n_samples);
 /* Resident range [oldest_index, head_index) and the ring capacity (any pointer may be NULL). */
 gc_status gc_stream_info(gc_stream* s, uint64_t* oldest_index, uint64_t* head_index, uint64_t* capacity_samples);
 /* Waits until every push so far has landed in HBM. */

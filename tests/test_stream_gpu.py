@@ -225,3 +225,34 @@ def test_closed_loop_on_a_cshort_ring(gctx, oracle):
         loop.set_input_format(gnsscorr.GC_IQ_F32)  # not while channels are bound
     loop.close()
     ring.close()
+
+
+def test_broadcast_of_one_pinned_block_into_several_rings(gctx, oracle):
+    """gc_stream_broadcast_pinned: the RF stream's copy for every GPU of a node (two rings on this GPU stand in for two GPUs):
+    both rings hold the block, channels reading either ring produce identical results."""
+    import gnsscorr
+    import torch
+    N, n_ep = 4000, 6
+    rng = np.random.Generator(np.random.PCG64(77))
+    x = (rng.standard_normal(N * (n_ep + 1)) + 1j * rng.standard_normal(N * (n_ep + 1))).astype(np.complex64)
+    host = torch.from_numpy(x.view(np.float32)).pin_memory()
+    rings = [gnsscorr.IqStream(gctx, N * 16, 2 * N) for _ in range(2)]
+    gnsscorr.stream_broadcast_pinned(rings, host.data_ptr(), x.size)
+    code = oracle.gps_l1_ca_code(7).astype(np.float32)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    outs = []
+    for r in rings:
+        r.synchronize()
+        assert r.info()[1] == x.size
+        b = gnsscorr.TrackingBatch(gctx, 1, 3, 1023)
+        b.set_code(0, code, shifts)
+        b.set_input_stream(0, r)
+        recs = [[gnsscorr.epoch_params(e * N, 0.2, 2e-3, 0.1, 0.25575, N) for e in range(n_ep)]]
+        outs.append(b.run(n_ep, gnsscorr.epoch_params_array(recs)))
+        b.close()
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0
+    with pytest.raises(gnsscorr.GnsscorrError, match="another sample format"):
+        other = gnsscorr.IqStream(gctx, N * 16, 2 * N, gnsscorr.GC_IQ_I16)
+        gnsscorr.stream_broadcast_pinned([rings[0], other], host.data_ptr(), 16)
+    for r in rings:
+        r.close()

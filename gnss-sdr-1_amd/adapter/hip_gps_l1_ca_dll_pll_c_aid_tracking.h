@@ -22,6 +22,7 @@
 #include "tracking_loop_maths.h"
 #include <cmath>
 #include <deque>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -48,20 +49,39 @@ struct CAidItem<std::complex<int16_t>>
 };
 }  // namespace gnsscorr
 
+//! which C-aid block: GPS L1 C/A, or GLONASS L1 / L2 C/A (glonass_l1_ca_dll_pll_c_aid_tracking_cc.cc, glonass_l2_..., and their _sc
+//! twins).  The GLONASS blocks differ in the constants, in the FDMA channel offset that the carrier loop filter's accumulator
+//! carries (so their "d_carrier_doppler_hz" is the NCO frequency, offset included), in a code-rate aiding that follows the CHANGE
+//! of that frequency (:738-741), and in a fixed 10-sample C/N0 window.
+struct CAidSignal
+{
+    bool is_glonass;
+    char system;
+    double code_rate_hz, code_length_chips, carrier_freq_hz, channel_spacing_hz;
+    static CAidSignal gps_l1() { return {false, 'G', 1.023e6, 1023.0, 1575.42e6, 0.0}; }
+    static CAidSignal glonass(int band) { return band == 2 ? CAidSignal{true, 'R', 0.511e6, 511.0, 1.246e9, 0.4375e6} : CAidSignal{true, 'R', 0.511e6, 511.0, 1.602e9, 0.5625e6}; }
+};
+
 template <class Item>
 class hip_gps_l1_ca_dll_pll_c_aid_tracking
 {
 public:
     hip_gps_l1_ca_dll_pll_c_aid_tracking(int64_t fs_in, uint32_t vector_length, float pll_bw_hz, float dll_bw_hz, float pll_bw_narrow_hz, float dll_bw_narrow_hz,
-        int32_t extend_correlation_ms, float early_late_space_chips, int cn0_samples = 20, int cn0_min = 25, int max_lock_fail = 50, double carrier_lock_th = 0.85)
-        : d_fs_in(fs_in), d_vector_length(vector_length), d_pll_bw_hz(pll_bw_hz), d_dll_bw_hz(dll_bw_hz), d_pll_bw_narrow_hz(pll_bw_narrow_hz),
+        int32_t extend_correlation_ms, float early_late_space_chips, int cn0_samples = 20, int cn0_min = 25, int max_lock_fail = 50, double carrier_lock_th = 0.85,
+        CAidSignal signal = CAidSignal::gps_l1())
+        : d_sig(signal), d_glonass_prn(gnsscorr::glonass_default_channels()), d_fs_in(fs_in), d_vector_length(vector_length), d_pll_bw_hz(pll_bw_hz), d_dll_bw_hz(dll_bw_hz), d_pll_bw_narrow_hz(pll_bw_narrow_hz),
           d_dll_bw_narrow_hz(dll_bw_narrow_hz), d_extend_correlation_ms(extend_correlation_ms), d_cn0_samples(cn0_samples), d_cn0_min(cn0_min),
           d_max_lock_fail(max_lock_fail), d_carrier_lock_threshold(carrier_lock_th)
     {
+        kCodeRateHz = d_sig.code_rate_hz;
+        kCodeLengthChips = d_sig.code_length_chips;
+        kL1FreqHz = d_sig.carrier_freq_hz;
+        if (d_sig.is_glonass) d_cn0_samples = 10;  // CN0_ESTIMATION_SAMPLES
+        cn0_samples = d_cn0_samples;
         d_correlation_length_samples = static_cast<int32_t>(d_vector_length);
         d_code_loop_filter.set_DLL_BW(d_dll_bw_hz);
         d_carrier_loop_filter.set_params(10.0, d_pll_bw_hz, 2);
-        d_ca_code.assign(1023, Item());
+        d_ca_code.assign(static_cast<size_t>(kCodeLengthChips), Item());
         d_correlator_outs_item.assign(3, Item());
         d_correlator_outs.assign(3, gr_complex(0, 0));
         d_local_code_shift_chips = {-early_late_space_chips, 0.0f, early_late_space_chips};
@@ -72,6 +92,8 @@ public:
 
     void set_channel(uint32_t channel) { d_channel = channel; }
     void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) { d_acquisition_gnss_synchro = p_gnss_synchro; }
+    //! GLONASS: slot -> frequency channel (almanac data; defaults to the reference's GLONASS_PRN table)
+    void set_glonass_channel_map(const std::map<uint32_t, int32_t>& prn_to_channel) { d_glonass_prn = prn_to_channel; }
 
     //! msg_handler_preamble_index (:78-88): the telemetry decoder's preamble time stamp enables the extended integration once
     void set_preamble_timestamp_s(double t)
@@ -92,6 +114,9 @@ public:
         d_acq_sample_stamp = d_acquisition_gnss_synchro->Acq_samplestamp_samples;
         const int64_t acq_trk_diff_samples = static_cast<int64_t>(d_sample_counter) - static_cast<int64_t>(d_acq_sample_stamp);
         const double acq_trk_diff_seconds = static_cast<double>(acq_trk_diff_samples) / static_cast<double>(d_fs_in);
+        // GLONASS: the slot's own carrier (band centre + channel x spacing) takes the place of the L1 frequency from here on
+        const double channel_offset_hz = d_sig.is_glonass ? d_sig.channel_spacing_hz * static_cast<double>(d_glonass_prn.at(d_acquisition_gnss_synchro->PRN)) : 0.0;
+        kL1FreqHz = d_sig.carrier_freq_hz + channel_offset_hz;
         const double radial_velocity = (kL1FreqHz + d_acq_carrier_doppler_hz) / kL1FreqHz;
         d_code_freq_chips = radial_velocity * kCodeRateHz;
         d_code_phase_step_chips = static_cast<double>(d_code_freq_chips) / static_cast<double>(d_fs_in);
@@ -105,13 +130,18 @@ public:
         if (corrected < 0) corrected = T_prn_mod_samples + corrected;
         d_acq_code_phase_samples = corrected;
         d_carrier_doppler_hz = d_acq_carrier_doppler_hz;
-        d_carrier_phase_step_rad = kTwoPi * d_carrier_doppler_hz / static_cast<double>(d_fs_in);
-        d_carrier_loop_filter.initialize(d_acq_carrier_doppler_hz);  // the carrier loop filter holds the Doppler accumulator
+        const double nco_frequency_hz = d_acq_carrier_doppler_hz + channel_offset_hz;  // d_carrier_frequency_hz of the GLONASS blocks
+        d_carrier_phase_step_rad = kTwoPi * nco_frequency_hz / static_cast<double>(d_fs_in);
+        d_carrier_loop_filter.initialize(nco_frequency_hz);  // the carrier loop filter holds the frequency accumulator
         d_code_loop_filter.initialize();
-        std::vector<float> chips(1023);
-        gc_gps_l1_ca_code_gen_float(chips.data(), static_cast<int32_t>(d_acquisition_gnss_synchro->PRN), 0);
-        for (int i = 0; i < 1023; i++) d_ca_code[i] = gnsscorr::CAidItem<Item>::from_float(gr_complex(chips[i], 0.0f));
-        multicorrelator_cpu.set_local_code_and_taps(1023, d_ca_code.data(), d_local_code_shift_chips.data());
+        const int n_chips = static_cast<int>(kCodeLengthChips);
+        std::vector<float> chips(n_chips);
+        if (d_sig.is_glonass)
+            gc_glonass_l1_ca_code_gen_float(chips.data(), 0);
+        else
+            gc_gps_l1_ca_code_gen_float(chips.data(), static_cast<int32_t>(d_acquisition_gnss_synchro->PRN), 0);
+        for (int i = 0; i < n_chips; i++) d_ca_code[i] = gnsscorr::CAidItem<Item>::from_float(gr_complex(chips[i], 0.0f));
+        multicorrelator_cpu.set_local_code_and_taps(n_chips, d_ca_code.data(), d_local_code_shift_chips.data());
         std::fill(d_correlator_outs.begin(), d_correlator_outs.end(), gr_complex(0, 0));
         d_carrier_lock_fail_counter = 0;
         d_rem_code_phase_samples = 0.0;
@@ -232,9 +262,12 @@ public:
                     {
                         // PLL: the filter output IS the Doppler (accumulator inside, Kaplan)
                         d_carr_phase_error_secs_Ti = pll_cloop_two_quadrant_atan(d_correlator_outs[1]) / kTwoPi;
+                        const double carrier_doppler_old_hz = d_carrier_doppler_hz;
                         d_carrier_doppler_hz = d_carrier_loop_filter.get_carrier_error(0.0, d_carr_phase_error_secs_Ti, CURRENT_INTEGRATION_TIME_S);
                         d_pll_to_dll_assist_secs_Ti = (d_carrier_doppler_hz * CURRENT_INTEGRATION_TIME_S) / kL1FreqHz;
-                        d_code_freq_chips = kCodeRateHz + ((d_carrier_doppler_hz * kCodeRateHz) / kL1FreqHz);
+                        // GLONASS blocks: the accumulator holds Doppler + channel offset, and the code rate follows its CHANGE (:738-741)
+                        const double aiding_hz = d_sig.is_glonass ? d_carrier_doppler_hz - carrier_doppler_old_hz : d_carrier_doppler_hz;
+                        d_code_freq_chips = kCodeRateHz + ((aiding_hz * kCodeRateHz) / kL1FreqHz);
                         // DLL
                         d_code_error_chips_Ti = dll_nc_e_minus_l_normalized(d_correlator_outs[0], d_correlator_outs[2]);
                         d_code_error_filt_chips_s = d_code_loop_filter.get_code_nco(d_code_error_chips_Ti);
@@ -262,7 +295,7 @@ public:
                         else
                             {
                                 d_cn0_estimation_counter = 0;
-                                d_CN0_SNV_dB_Hz = cn0_svn_estimator(d_Prompt_buffer.data(), d_cn0_samples, 0.001);
+                                d_CN0_SNV_dB_Hz = cn0_svn_estimator(d_Prompt_buffer.data(), d_cn0_samples, 0.001);  // both code periods are 1 ms
                                 d_carrier_lock_test = carrier_lock_detector(d_Prompt_buffer.data(), d_cn0_samples);
                                 if (d_carrier_lock_test < d_carrier_lock_threshold or d_CN0_SNV_dB_Hz < d_cn0_min)
                                     d_carrier_lock_fail_counter++;
@@ -289,7 +322,7 @@ public:
         else
             {
                 std::fill(d_correlator_outs.begin(), d_correlator_outs.end(), gr_complex(0, 0));
-                current_synchro_data.System = 'G';
+                current_synchro_data.System = d_sig.system;
                 current_synchro_data.Tracking_sample_counter = d_sample_counter + static_cast<uint64_t>(d_correlation_length_samples);
             }
         current_synchro_data.fs = d_fs_in;
@@ -311,11 +344,12 @@ public:
     gc_status last_status() const { return multicorrelator_cpu.last_status(); }
 
 private:
-    static constexpr double kTwoPi = 6.283185307179586;  // GPS_TWO_PI
-    static constexpr double kCodeRateHz = 1.023e6;
-    static constexpr double kCodeLengthChips = 1023.0;
-    static constexpr double kL1FreqHz = 1575.42e6;
+    static constexpr double kTwoPi = 6.283185307179586;  // GPS_TWO_PI / GLONASS_TWO_PI
+    double kCodeRateHz = 1.023e6, kCodeLengthChips = 1023.0;
+    double kL1FreqHz = 1575.42e6;  // the carrier the code rate is aided against (GLONASS: the slot's own, set in start_tracking)
 
+    CAidSignal d_sig;
+    std::map<uint32_t, int32_t> d_glonass_prn;
     int64_t d_fs_in;
     uint32_t d_vector_length;
     float d_pll_bw_hz, d_dll_bw_hz, d_pll_bw_narrow_hz, d_dll_bw_narrow_hz;
@@ -346,14 +380,16 @@ private:
     std::vector<int> d_events;
 };
 
-//! TrackingInterface adapter; item_type "gr_complex" or "cshort" picks the block (gps_l1_ca_dll_pll_c_aid_tracking.cc:62-125)
-class GpsL1CaDllPllCAidTrackingHip : public TrackingInterface
+//! TrackingInterface adapter; item_type "gr_complex" or "cshort" picks the block (gps_l1_ca_dll_pll_c_aid_tracking.cc:62-125,
+//! glonass_l1_ca_dll_pll_c_aid_tracking.cc, glonass_l2_ca_dll_pll_c_aid_tracking.cc).  BAND: 0 = GPS L1 C/A, 1 / 2 = GLONASS L1 / L2 C/A
+template <int BAND>
+class DllPllCAidTrackingHip : public TrackingInterface
 {
 public:
     typedef hip_gps_l1_ca_dll_pll_c_aid_tracking<gr_complex> block_cc;
     typedef hip_gps_l1_ca_dll_pll_c_aid_tracking<std::complex<int16_t>> block_sc;
 
-    GpsL1CaDllPllCAidTrackingHip(ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    DllPllCAidTrackingHip(ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
         : role_(role), in_streams_(in_streams), out_streams_(out_streams)
     {
         item_type_ = configuration->property(role + ".item_type", std::string("gr_complex"));
@@ -365,23 +401,27 @@ public:
         const float dll_bw_narrow_hz = configuration->property(role + ".dll_bw_narrow_hz", 2.0f);
         const int extend_correlation_ms = configuration->property(role + ".extend_correlation_ms", 1);
         const float early_late_space_chips = configuration->property(role + ".early_late_space_chips", 0.5f);
-        vector_length_ = std::round(fs_in / (1.023e6 / 1023.0));
+        const CAidSignal sig = BAND == 0 ? CAidSignal::gps_l1() : CAidSignal::glonass(BAND);
+        vector_length_ = std::round(fs_in / (sig.code_rate_hz / sig.code_length_chips));
         const int cn0_samples = configuration->property(role + ".cn0_samples", 20), cn0_min = configuration->property(role + ".cn0_min", 25);
         const int max_lock_fail = configuration->property(role + ".max_lock_fail", 50);
         const double lock_th = configuration->property(role + ".carrier_lock_th", 0.85);
         if (item_type_ == "cshort")
             tracking_sc_ = std::make_shared<block_sc>(fs_in, vector_length_, pll_bw_hz, dll_bw_hz, pll_bw_narrow_hz, dll_bw_narrow_hz, extend_correlation_ms,
-                early_late_space_chips, cn0_samples, cn0_min, max_lock_fail, lock_th);
+                early_late_space_chips, cn0_samples, cn0_min, max_lock_fail, lock_th, sig);
         else
             {
                 item_type_ = "gr_complex";
                 tracking_cc_ = std::make_shared<block_cc>(fs_in, vector_length_, pll_bw_hz, dll_bw_hz, pll_bw_narrow_hz, dll_bw_narrow_hz, extend_correlation_ms,
-                    early_late_space_chips, cn0_samples, cn0_min, max_lock_fail, lock_th);
+                    early_late_space_chips, cn0_samples, cn0_min, max_lock_fail, lock_th, sig);
             }
     }
 
     std::string role() override { return role_; }
-    std::string implementation() override { return "GPS_L1_CA_DLL_PLL_C_Aid_Tracking_HIP"; }
+    std::string implementation() override
+    {
+        return BAND == 0 ? "GPS_L1_CA_DLL_PLL_C_Aid_Tracking_HIP" : BAND == 1 ? "GLONASS_L1_CA_DLL_PLL_C_Aid_Tracking_HIP" : "GLONASS_L2_CA_DLL_PLL_C_Aid_Tracking_HIP";
+    }
     size_t item_size() override { return item_type_ == "cshort" ? sizeof(std::complex<int16_t>) : sizeof(gr_complex); }
     void start_tracking() override { tracking_cc_ ? tracking_cc_->start_tracking() : tracking_sc_->start_tracking(); }
     void stop_tracking() override { tracking_cc_ ? tracking_cc_->stop_tracking() : tracking_sc_->stop_tracking(); }
@@ -399,5 +439,9 @@ private:
     unsigned int in_streams_, out_streams_;
     unsigned int vector_length_ = 0;
 };
+
+using GpsL1CaDllPllCAidTrackingHip = DllPllCAidTrackingHip<0>;
+using GlonassL1CaDllPllCAidTrackingHip = DllPllCAidTrackingHip<1>;
+using GlonassL2CaDllPllCAidTrackingHip = DllPllCAidTrackingHip<2>;
 
 #endif  // GNSSCORR_HIP_GPS_L1_CA_DLL_PLL_C_AID_TRACKING_H_

@@ -953,6 +953,61 @@ static void test_tracking_group()
     gc_ctx_destroy(ctx);
 }
 
+static void test_glonass_c_aid_tracking()
+{
+    // the GLONASS twins of the C-aid block (glonass_l1_ca_dll_pll_c_aid_tracking_cc): FDMA channel in the loop filter's accumulator
+    const double fs = 6.625e6, fd = -1800.0, cn0 = 47.0, delay_samples = 3000.0;
+    const double f_channel = 4 * 562500.0;  // slot 21 = channel +4
+    std::vector<float> code(511);
+    gc_glonass_l1_ca_code_gen_float(code.data(), 0);
+    auto x = synth(code, 0.511e6, 1.602e9 + f_channel, fs, 6625 * 900, fd, 511.0 - delay_samples * 0.511e6 / fs, cn0, 81);
+    for (size_t i = 0; i < x.size(); i++)
+        {
+            const double ph = 2.0 * M_PI * std::fmod(f_channel * static_cast<double>(i) / fs, 1.0);
+            x[i] *= gr_complex(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+        }
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "6625000");
+    config.set_property("Tracking_1G.pll_bw_hz", "35.0");
+    config.set_property("Tracking_1G.dll_bw_hz", "3.0");
+    Gnss_Synchro syn;
+    syn.System = 'R';
+    syn.Signal[0] = '1';
+    syn.Signal[1] = 'G';
+    syn.PRN = 21;
+    syn.Acq_delay_samples = delay_samples;
+    syn.Acq_doppler_hz = fd - 20.0;
+    syn.Acq_samplestamp_samples = 0;
+    GlonassL1CaDllPllCAidTrackingHip trk(&config, "Tracking_1G", 1, 1);
+    EXPECT(trk.implementation() == "GLONASS_L1_CA_DLL_PLL_C_Aid_Tracking_HIP" && trk.vector_length() == 6625, "GLONASS C-aid adapter");
+    trk.set_gnss_synchro(&syn);
+    trk.start_tracking();
+    auto blk = trk.block_gr_complex();
+    size_t pos = 0;
+    int epochs = 0, averaged = 0;
+    double mean_nco = 0.0;
+    Gnss_Synchro out;
+    while (pos + blk->required_input_items() <= x.size() && blk->tracking_enabled())
+        {
+            int produced = 0;
+            pos += blk->work(x.data() + pos, static_cast<int>(x.size() - pos), &out, &produced);
+            if (epochs >= 400)
+                {
+                    mean_nco += blk->carrier_doppler_hz();  // the accumulator of this block holds Doppler + channel offset
+                    averaged++;
+                }
+            epochs++;
+        }
+    mean_nco /= std::max(1, averaged);
+    EXPECT(blk->last_status() == GC_OK, "GLONASS C-aid: engine status %d (%s)", blk->last_status(), gc_last_error());
+    EXPECT(blk->tracking_enabled() && blk->events().empty() && epochs > 850, "GLONASS C-aid: lost lock after %d periods", epochs);
+    EXPECT(std::fabs(mean_nco - (fd + f_channel)) < 3.0, "GLONASS C-aid: mean NCO frequency %.2f Hz, truth %.2f", mean_nco, fd + f_channel);
+    EXPECT(blk->carrier_lock_test() > 0.85 && std::fabs(blk->cn0_db_hz() - cn0) < 3.5, "GLONASS C-aid: C/N0 %.1f dB-Hz, lock test %.3f", blk->cn0_db_hz(),
+        blk->carrier_lock_test());
+    std::printf("GLONASS L1 C/A C-aid (slot 21, channel +4): %d periods, mean NCO frequency %.2f Hz (truth %.2f), C/N0 %.1f dB-Hz, lock test %.3f\n", epochs, mean_nco,
+        fd + f_channel, blk->cn0_db_hz(), blk->carrier_lock_test());
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -1000,6 +1055,7 @@ int main()
     test_beidou_b3i_and_gps_l2c();
     test_glonass_fdma_tracking();
     test_gps_c_aid_tracking();
+    test_glonass_c_aid_tracking();
     test_device_loop_block();
     test_tracking_group();
     test_loss_of_lock();

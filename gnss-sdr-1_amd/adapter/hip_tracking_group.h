@@ -25,9 +25,11 @@
 class hip_tracking_group
 {
 public:
-    /*! ctx / ring: the GPU context and the RF stream the channels read (GC_IQ_F32); conf: the Dll_Pll_Conf every channel of the
-     *  group shares (signal, loop settings); n_channels: slots */
-    hip_tracking_group(gc_ctx* ctx, gc_stream* ring, const Dll_Pll_Conf& conf, int n_channels) : trk_parameters(conf), d_ring(ring), d_n(n_channels)
+    /*! ctx / ring: the GPU context and the RF stream the channels read; conf: the Dll_Pll_Conf every channel of the group shares
+     *  (signal, loop settings); n_channels: slots; iq_format: the ring's sample format (GC_IQ_F32 gr_complex, GC_IQ_I16 cshort,
+     *  GC_IQ_I8 cbyte -- integer samples are converted on load, the stream crosses PCIe and sits in HBM in its native size) */
+    hip_tracking_group(gc_ctx* ctx, gc_stream* ring, const Dll_Pll_Conf& conf, int n_channels, int iq_format = GC_IQ_F32)
+        : trk_parameters(conf), d_ring(ring), d_n(n_channels)
     {
         if (!gnsscorr::trk_signal_constants(trk_parameters.system, std::string(trk_parameters.signal), &d_sig))
             {
@@ -36,6 +38,7 @@ public:
             }
         if (!d_sig.has_pilot) trk_parameters.track_pilot = false;
         d_status = gc_trk_loop_create(ctx, n_channels, static_cast<int>(d_sig.code_length_chips * d_sig.code_samples_per_chip), &d_loop);
+        if (d_status == GC_OK) d_status = gc_trk_loop_set_input_format(d_loop, iq_format);
         for (int ch = 0; ch < n_channels && d_status == GC_OK; ch++) d_status = gc_trk_loop_set_input_stream(d_loop, ch, ring);
         d_acq.resize(n_channels);
         d_active.assign(n_channels, 0);

@@ -849,7 +849,7 @@ static void test_device_loop_block()
 
 // All channels of a signal as one object on one RF stream ring: four satellites in the stream, six slots, hand-overs at different
 // times, one slot pointed at a satellite that is not there (it loses lock and frees itself), one launch per pushed block.
-static void test_tracking_group()
+static void test_tracking_group(int iq_format)
 {
     const double fs = 4e6;
     const int prns[4] = {3, 11, 19, 27};
@@ -884,9 +884,17 @@ static void test_tracking_group()
     gc_ctx* ctx = nullptr;
     gc_stream* ring = nullptr;
     EXPECT(gc_ctx_create(0, &ctx) == GC_OK, "group: context");
-    EXPECT(gc_stream_create(ctx, GC_IQ_F32, 4000 * 128, 8000, &ring) == GC_OK, "group: ring (%s)", gc_last_error());
+    EXPECT(gc_stream_create(ctx, iq_format, 4000 * 128, 8000, &ring) == GC_OK, "group: ring (%s)", gc_last_error());
+    // a cshort front end: 12 significant bits around unit-variance noise
+    std::vector<std::complex<int16_t>> xs;
+    if (iq_format == GC_IQ_I16)
+        {
+            xs.resize(n);
+            for (size_t i = 0; i < n; i++)
+                xs[i] = std::complex<int16_t>(static_cast<int16_t>(std::lrint(x[i].real() * 256.0f)), static_cast<int16_t>(std::lrint(x[i].imag() * 256.0f)));
+        }
     {
-        hip_tracking_group group(ctx, ring, conf, 6);
+        hip_tracking_group group(ctx, ring, conf, 6, iq_format);
         EXPECT(group.last_status() == GC_OK, "group: status %d (%s)", group.last_status(), gc_last_error());
         auto acq_of = [&](int k, uint64_t stamp) {
             Gnss_Synchro a;
@@ -904,7 +912,8 @@ static void test_tracking_group()
         int launches = 0;
         for (size_t pos = 0, b = 0; pos + block <= n; pos += block, b++)
             {
-                EXPECT(gc_stream_push(ring, x.data() + pos, block, nullptr) == GC_OK, "group: push (%s)", gc_last_error());
+                const void* src = iq_format == GC_IQ_I16 ? static_cast<const void*>(xs.data() + pos) : static_cast<const void*>(x.data() + pos);
+                EXPECT(gc_stream_push(ring, src, block, nullptr) == GC_OK, "group: push (%s)", gc_last_error());
                 // hand-overs as acquisitions would deliver them; the code delay is relative to the acquisition stamp (a multiple of a code period here)
                 if (b == 0)
                     {
@@ -946,8 +955,8 @@ static void test_tracking_group()
         EXPECT(!group.active(5) && group.events(5).size() == 1 && group.events(5)[0] == 3, "group: the ghost satellite's slot did not report loss of lock (%zu events)",
             group.events(5).size());
         EXPECT(!group.active(3) && out[3].empty(), "group: the unused slot produced %zu items", out[3].size());
-        std::printf("tracking group: 4 satellites + 1 ghost on 6 slots, %d launches for %.0f ms of signal: %zu / %zu / %zu / %zu Gnss_Synchro, ghost lost lock after %zu\n", launches,
-            n / fs * 1e3, out[0].size(), out[4].size(), out[2].size(), out[1].size(), out[5].size());
+        std::printf("tracking group (%s ring): 4 satellites + 1 ghost on 6 slots, %d launches for %.0f ms of signal: %zu / %zu / %zu / %zu Gnss_Synchro, ghost lost lock after %zu\n",
+            iq_format == GC_IQ_I16 ? "cshort" : "gr_complex", launches, n / fs * 1e3, out[0].size(), out[4].size(), out[2].size(), out[1].size(), out[5].size());
     }
     gc_stream_destroy(ring);
     gc_ctx_destroy(ctx);
@@ -1057,7 +1066,8 @@ int main()
     test_gps_c_aid_tracking();
     test_glonass_c_aid_tracking();
     test_device_loop_block();
-    test_tracking_group();
+    test_tracking_group(GC_IQ_F32);
+    test_tracking_group(GC_IQ_I16);
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

@@ -8,6 +8,7 @@
 #include "dll_pll_tracking_adapters.h"
 #include "hip_glonass_ca_dll_pll_tracking.h"
 #include "hip_gps_l1_ca_dll_pll_c_aid_tracking.h"
+#include "hip_acquisition_bank.h"
 #include "hip_tracking_group.h"
 #include "pcps_acquisition_adapters.h"
 #include <chrono>
@@ -1017,6 +1018,85 @@ static void test_glonass_c_aid_tracking()
         fd + f_channel, blk->cn0_db_hz(), blk->carrier_lock_test());
 }
 
+// The two stages as two objects on one ring: hip_acquisition_bank searches all 32 GPS PRNs at once on the first block, its detections
+// go straight into hip_tracking_group slots, the rest of the stream is tracked one launch per pushed block.
+static void test_acquisition_bank_into_tracking_group()
+{
+    const double fs = 4e6;
+    const int prns[3] = {5, 14, 23};
+    const double dopplers[3] = {-3300.0, 450.0, 2750.0};
+    const double delays[3] = {250.0, 2020.0, 3700.0};
+    const size_t n = 4000 * 600;
+    std::vector<gr_complex> x;
+    for (int k = 0; k < 3; k++)
+        {
+            std::vector<float> code(1023);
+            gc_gps_l1_ca_code_gen_float(code.data(), prns[k], 0);
+            auto with_noise = synth(code, 1.023e6, 1575.42e6, fs, n, dopplers[k], 1023.0 - delays[k] * 1.023e6 / fs, 48.0, 90 + k);
+            if (k == 0)
+                x = with_noise;
+            else
+                {
+                    auto only_noise = synth(code, 1.023e6, 1575.42e6, fs, n, dopplers[k], 1023.0 - delays[k] * 1.023e6 / fs, -300.0, 90 + k);
+                    for (size_t i = 0; i < n; i++) x[i] += with_noise[i] - only_noise[i];
+                }
+        }
+    InMemoryConfiguration config;
+    config.set_property("GNSS-SDR.internal_fs_sps", "4000000");
+    config.set_property("Tracking_1C.pll_bw_hz", "50.0");
+    GpsL1CaDllPllTrackingHip conf_source(&config, "Tracking_1C", 1, 1);
+    gc_ctx* ctx = nullptr;
+    gc_stream* ring = nullptr;
+    EXPECT(gc_ctx_create(0, &ctx) == GC_OK && gc_stream_create(ctx, GC_IQ_F32, 4000 * 128, 8000, &ring) == GC_OK, "bank: ring (%s)", gc_last_error());
+    {
+        std::vector<uint32_t> all;
+        for (uint32_t p = 1; p <= 32; p++) all.push_back(p);
+        // statistic = peak / N^4 / input power: noise cells average 1 / N, the largest of 32 x 100 x 4000 about 16 / N; 48 dB-Hz gives 63 / N
+        hip_acquisition_bank bank(ctx, ring, 'G', "1C", all, 4000000, 5000, 100, 30.0f / 4000.0f);
+        hip_tracking_group group(ctx, ring, conf_source.conf(), 8);
+        EXPECT(bank.last_status() == GC_OK && bank.consumed_samples() == 4000 && group.last_status() == GC_OK, "bank: status %d / %d (%s)", bank.last_status(),
+            group.last_status(), gc_last_error());
+        std::vector<std::vector<Gnss_Synchro>> out;
+        std::vector<Gnss_Synchro> detections;
+        const size_t block = 4000 * 40;
+        for (size_t pos = 0, b = 0; pos + block <= n; pos += block, b++)
+            {
+                EXPECT(gc_stream_push(ring, x.data() + pos, block, nullptr) == GC_OK, "bank: push (%s)", gc_last_error());
+                if (b == 0)
+                    {
+                        detections = bank.search(0);
+                        EXPECT(bank.last_status() == GC_OK, "bank: search status %d (%s)", bank.last_status(), gc_last_error());
+                        for (size_t d = 0; d < detections.size() && d < 8; d++)
+                            EXPECT(group.start_tracking(static_cast<int>(d), detections[d], detections[d].Acq_samplestamp_samples) == GC_OK, "group: hand-over (%s)",
+                                gc_last_error());
+                    }
+                EXPECT(group.run(out) >= 0, "group: run status %d (%s)", group.last_status(), gc_last_error());
+            }
+        EXPECT(detections.size() == 3, "bank: %zu detections", detections.size());
+        for (size_t d = 0; d < detections.size(); d++)
+            {
+                int k = -1;
+                for (int j = 0; j < 3; j++)
+                    if (static_cast<uint32_t>(prns[j]) == detections[d].PRN) k = j;
+                EXPECT(k >= 0, "bank: false alarm on PRN %u", detections[d].PRN);
+                if (k < 0) continue;
+                EXPECT(std::fabs(detections[d].Acq_delay_samples - delays[k]) <= 1.0 && std::fabs(detections[d].Acq_doppler_hz - dopplers[k]) <= 60.0,
+                    "bank: PRN %d at %.0f samples / %.0f Hz", prns[k], detections[d].Acq_delay_samples, detections[d].Acq_doppler_hz);
+                const auto& o = out[d];
+                double mean = 0.0;
+                int cnt = 0;
+                for (size_t i = o.size() > 150 ? o.size() - 150 : 0; i < o.size(); i++, cnt++) mean += o[i].Carrier_Doppler_hz;
+                mean /= std::max(1, cnt);
+                EXPECT(o.size() > 570 && std::fabs(mean - dopplers[k]) < 3.0 && o.back().CN0_dB_hz > 42.0, "group: PRN %d: %zu items, mean Doppler %.2f (truth %.2f), C/N0 %.1f",
+                    prns[k], o.size(), mean, dopplers[k], o.empty() ? 0.0 : o.back().CN0_dB_hz);
+            }
+        std::printf("acquisition bank -> tracking group: 32 PRNs searched at once, %zu detections (PRN %u, %u, %u), all tracked to the end of the stream\n", detections.size(),
+            detections.size() > 0 ? detections[0].PRN : 0, detections.size() > 1 ? detections[1].PRN : 0, detections.size() > 2 ? detections[2].PRN : 0);
+    }
+    gc_stream_destroy(ring);
+    gc_ctx_destroy(ctx);
+}
+
 static void test_loss_of_lock()
 {
     // noise only: the lock detectors must raise message 3 and put the block in standby
@@ -1068,6 +1148,7 @@ int main()
     test_device_loop_block();
     test_tracking_group(GC_IQ_F32);
     test_tracking_group(GC_IQ_I16);
+    test_acquisition_bank_into_tracking_group();
     test_loss_of_lock();
     std::printf(g_fail ? "%d FAILURES\n" : "tracking self-test passed\n", g_fail);
     return g_fail ? 1 : 0;

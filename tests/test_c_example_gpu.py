@@ -30,6 +30,7 @@ def test_c_example_runs(tmp_path):
     assert "NOT LOCKED" not in p.stdout
 
 
+@pytest.mark.gpu
 def test_python_receiver_front_end_example():
     """examples/receiver_bench.py: ring push -> 32-PRN PCPS search -> hand-over into free slots of one closed-loop engine ->
     tracking, at 4 Msps for half a second: every satellite of the stream found (no false alarm) and tracked to within 5 Hz."""

@@ -68,7 +68,9 @@ def _compare(rec, ref, n_taps, tol=3e-3, abs_tol=0.0):
         assert np.max(np.abs(ga - r["accu"])) <= max(tol * max(scale, np.max(np.abs(r["accu"]))), 4 * abs_tol), k
         loose = abs_tol / scale  # relative size of one sample in a tap (0 for the fixed scenarios)
         assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.05 + 40 * loose, k
-        assert abs(float(g["code_error_chips"]) - r["cerr"]) < 3e-3 + 2 * loose, k
+        # the discriminator divides by |E| + |L|: a chip-edge sample weighs 1 / that sum, which is small when the loop is far off
+        el = float(np.sum(np.abs(r["accu"][[1, 3]]))) if r["accu"] is not None else scale
+        assert abs(float(g["code_error_chips"]) - r["cerr"]) < 3e-3 + 2 * loose + 2 * abs_tol / max(el, 1e-9), k
         assert abs(float(g["cn0_db_hz"]) - r["cn0"]) < 0.05 + 40 * loose and abs(float(g["carrier_lock_test"]) - r["lock_test"]) < 2e-3 + 2 * loose, k
 
 

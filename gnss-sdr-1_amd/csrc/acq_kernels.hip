@@ -648,8 +648,12 @@ static __device__ __forceinline__ MaxPair max_pair(MaxPair a, MaxPair b)
     return take_b ? b : a;
 }
 
+#ifndef ACQ_COLS_WAVES
+#define ACQ_COLS_WAVES 1  // minimum waves per SIMD the columns kernel is compiled for.  4 (128 registers, a fourth workgroup per CU) was
+                          // measured: the 25-point column transform then spills 43 registers and a search takes 0.60 instead of 0.50 ms
+#endif
 template <int N1, bool INV, int EPI>
-__global__ __launch_bounds__(ACQ_THREADS) void acq_cols_kernel(AcqFftPlan plan, const float2* __restrict__ Q,
+__global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ACQ_COLS_WAVES : 1)) void acq_cols_kernel(AcqFftPlan plan, const float2* __restrict__ Q,
     float2* __restrict__ out, AcqMagArgs mag)
 {
     const int N2 = plan.N2, N = plan.N;

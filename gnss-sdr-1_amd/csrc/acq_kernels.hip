@@ -23,13 +23,35 @@
 
 #define ACQ_THREADS 256
 
+#ifndef ACQ_PK_CMUL
+#define ACQ_PK_CMUL 0  // 1: complex multiplies as two hand-written packed-FP32 instructions.  Measured: the compiler already emits the same
+                      // v_pk_mul_f32 + v_pk_fma_f32 pair from the plain form (identical counts in the row kernel), and the inline-asm version
+                      // schedules worse (0.55 instead of 0.50 ms per search): kept as a knob
+#endif
+typedef float acq_f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
+#if ACQ_PK_CMUL
+    // t = (-ay*by, ay*bx); r = (ax*bx + t.lo, ax*by + t.hi): the operand halves are picked with op_sel / op_sel_hi, the sign with neg_lo
+    acq_f32x2 va = {a.x, a.y}, vb = {b.x, b.y}, t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(va), "v"(vb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+    return make_float2(r.x, r.y);
+#else
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+#endif
 }
 static __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)  // a * conj(b)
 {
+#if ACQ_PK_CMUL
+    // t = (ay*by, ay*bx); r = (ax*bx + t.lo, -ax*by + t.hi)
+    acq_f32x2 va = {a.x, a.y}, vb = {b.x, b.y}, t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(va), "v"(vb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+    return make_float2(r.x, r.y);
+#else
     return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+#endif
 }
 static __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 static __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }

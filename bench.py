@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=256, help="code periods per channel per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-acq", action="store_true")
+    ap.add_argument("--acq-reps", type=int, default=5, help="timed acquisition searches (profiles/collect.sh counts on this)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-shared", action="store_true", help="skip the shared-stream extra (clean rocprof runs)")
     args = ap.parse_args()
@@ -485,12 +486,15 @@ def main():
 
         # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----
         if not args.no_acq:
-            acq = gnsscorr.PcpsAcquisition(ctx, 32, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,
-                5000, 250, max_dwells=2, use_cfar=False, num_doppler_bins_override=41)
-            for s in range(32):
+            n_sat, n_bins_acq, n_dw = 32, 41, 2
+            acq = gnsscorr.PcpsAcquisition(ctx, n_sat, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,
+                5000, 250, max_dwells=n_dw, use_cfar=False, num_doppler_bins_override=n_bins_acq)
+            sampled = []
+            for s in range(n_sat):
                 code = gps_ca_code(s + 1)
                 idx = np.minimum((np.arange(N_EPOCH) * (1.023e6 / FS)).astype(np.int64), 1022)
-                acq.set_local_code(s, code[idx].astype(np.complex64))
+                sampled.append(code[idx].astype(np.complex64))
+                acq.set_local_code(s, sampled[-1])
             x = streams[0]
             def acq_search():
                 acq.reset()
@@ -498,14 +502,14 @@ def main():
                 acq.dwell_enqueue(x.data_ptr() + 8 * N_EPOCH, stream)
             acq_search()
             torch.cuda.synchronize()
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 5
-            a0.record()
-            for _ in range(reps):
+            reps = args.acq_reps
+            aev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a0, a1 in aev:
+                a0.record()
                 acq_search()
-            a1.record()
+                a1.record()
             torch.cuda.synchronize()
-            acq_ms = a0.elapsed_time(a1) / reps
+            acq_ms = float(np.mean([a0.elapsed_time(a1) for a0, a1 in aev]))
             # sanity: stream 0 carries PRN 1 only -- it must win, at its code phase and in its Doppler bin
             ares = acq.fetch_results(stream)
             stats = np.array([r.test_statistics for r in ares])
@@ -514,8 +518,46 @@ def main():
             d_err = abs(ares[0].indext - want_delay)
             assert int(np.argmax(stats)) == 0 and min(d_err, N_EPOCH - d_err) <= 26 and abs(ares[0].doppler_hz - t_a["doppler"]) <= 250, \
                 ("acquisition lost PRN 1", stats[:4], ares[0].indext, want_delay, ares[0].doppler_hz, t_a["doppler"])
-            extra["acquisition"] = {"dwells_per_s": 64 / (acq_ms * 1e-3), "ms_per_search": acq_ms,
-                "workload": "GPS L1 C/A PCPS, 25 Msps, N=25000, 32 PRNs x 41 Doppler bins x 2 dwells"}
+            # Algorithmic bytes per (PRN, bin, dwell) cell: read X 8N + read conj-FFT(code) 8N + write |.|^2 4N,
+            # + 4N read when a later dwell accumulates: 20N for dwell 1, 24N for dwell 2
+            cells = n_sat * n_bins_acq
+            acq_alg = float(cells * N_EPOCH * (20 + 24))
+            acq_gbps = acq_alg / (acq_ms * 1e-3) / 1e9
+            aroof = {"bound": "hbm", "achieved": acq_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": acq_gbps / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_search": acq_alg, "search_ms": acq_ms,
+                "note": "whole search (2 dwells: shared forward transforms, inverse row + column passes of every cell, statistics) timed with "
+                        "HIP events on the launch stream; achieved = algorithmic bytes / that time", "traffic": None}
+            apath = os.path.join(ROOT, "profiles", "acq_latest.json")
+            if os.path.exists(apath):
+                try:
+                    aj = json.load(open(apath))
+                    aroof["traffic"] = aj.get("hbm_bytes_per_search")
+                    aroof["traffic_source"] = "profiles/acq_latest.json (round %s rocprofv3 PMC passes of this workload; not measured in this run)" % aj.get("round")
+                    aroof["dominant_kernel"] = aj.get("dominant_kernel")
+                    aroof["dominant_kernel_us_per_launch"] = aj.get("dominant_kernel_us")
+                except Exception:
+                    pass
+            extra["acquisition"] = {"dwells_per_s": n_sat * n_dw / (acq_ms * 1e-3), "ms_per_search": acq_ms,
+                "workload": "GPS L1 C/A PCPS, 25 Msps, N=25000, 32 PRNs x 41 Doppler bins x 2 dwells", "roofline": aroof}
+            if not args.no_cpu and world == 1:
+                # CPU baseline of the same search: the oracle's acquisition_core restatement (own float64 mixed-radix FFT, gcc -O3
+                # -march=native, 1 thread) on a bounded sample: PRN-dwells of the same block sizes and Doppler grid
+                from oracle import Oracle
+                orc = Oracle(native=True)
+                xh = x[:2 * N_EPOCH].cpu().numpy().view(np.complex64).reshape(-1)
+                pc = orc.pcps(fs_in=FS, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(FS) * np.float32(0.001), samples_per_code=25000.0,
+                    samples_per_chip=25, doppler_max=5125, doppler_step=250, max_dwells=n_dw)  # ceil(10250 / 250) = 41 bins
+                pc.set_local_code(sampled[0])
+                n_done, t0c = 0, time.perf_counter()
+                while time.perf_counter() - t0c < args.cpu_seconds * 0.5:
+                    pc.reset_grid()
+                    for d_ in range(n_dw):
+                        pc.core(xh[d_ * N_EPOCH:])
+                        n_done += 1
+                dtc = time.perf_counter() - t0c
+                extra["acquisition"]["cpu_baseline"] = {"value": n_done / dtc, "unit": "dwells/s", "cores": 1, "kind": "port",
+                    "sample": "%d PRN-dwells (41 Doppler bins x N=25000 each, 2-dwell searches of PRN 1) in %.1f s, oracle PCPS "
+                              "(acquisition_core restatement with its own float64 FFT, gcc -O3 -march=native), 1 thread" % (n_done, dtc)}
             acq.close()
 
         cpu = None
@@ -543,11 +585,15 @@ def main():
                 extra["cpu_baseline_all_cores"] = {"value": vt, "unit": "Msamples/s", "cores": n_thr, "kind": "port",
                     "sample": "%d channel-epochs in %.1f s, one thread per channel" % (nt, dtt)}
 
-        traffic = None
+        # HBM traffic of the tracking kernel: rocprofv3 PMC counters cannot be read from inside the run, so the figure comes from
+        # the committed counter passes of the SAME workload (profiles/collect.sh) and is labelled as such; null for another workload
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and E == 256:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic_latest.json (round %s rocprofv3 PMC passes: FETCH_SIZE x 2 + WRITE_SIZE on this workload; not measured in this run)" % tj.get("round")
             except Exception:
                 traffic = None
         result = {
@@ -560,7 +606,7 @@ def main():
                 "channels_per_gpu": N_CHANNELS, "epochs_per_step": E, "samples_per_epoch": N_EPOCH,
                 "parallelism": "channels sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 # <NTAPS, HDR, HDC, FMT = GC_IQ_F32, CC, SC16>: the name rocprofv3 prints
                 "kernel": "trk_multicorrelator_kernel<3, false, false, 0, false, false>", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_bytes},

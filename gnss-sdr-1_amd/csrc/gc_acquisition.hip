@@ -478,19 +478,26 @@ gc_status gc_acq_dwell_stream(gc_acq* a, gc_stream* s, uint64_t first_index, gc_
     GC_REQUIRE(s->iq_format == a->iq_format, "gc_acq_dwell_stream: stream format %d, acquisition format %d (gc_acq_set_input_format)",
         s->iq_format, a->iq_format);
     GC_REQUIRE(a->consumed <= s->mirror, "gc_acq_dwell_stream: the block of %u samples is longer than the stream's max_window", a->consumed);
-    uint64_t oldest = 0, head = 0;
-    gc_stream_info(s, &oldest, &head, nullptr);
-    GC_REQUIRE(first_index >= oldest && first_index + a->consumed <= head,
-        "gc_acq_dwell_stream: block [%llu, +%u) is not inside the stream's resident samples [%llu, %llu)",
-        (unsigned long long)first_index, a->consumed, (unsigned long long)oldest, (unsigned long long)head);
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
     hipStream_t st = a->ctx->stream;
-    gc_status rs = gc_stream_begin_read(s, st);
+    // the block is protected against eviction from here (reserved before the residency check and the launch)
+    gc_stream_ticket t;
+    gc_status rs = gc_stream_begin_read(s, st, first_index, &t);
     if (rs != GC_OK) return rs;
+    if (first_index + a->consumed > t.head)
+        {
+            gc_stream_cancel_read(s, t);
+            return gc_fail(GC_ERR_INVALID, "gc_acq_dwell_stream: block [%llu, +%u) is not inside the stream's resident samples [%llu, %llu)",
+                (unsigned long long)first_index, a->consumed, (unsigned long long)t.oldest, (unsigned long long)t.head);
+        }
     rs = acq_enqueue(a, s->d_ring + (first_index % s->capacity) * s->elem, a->iq_format, st);
-    if (rs != GC_OK) return rs;
-    rs = gc_stream_end_read(s, st, first_index);
+    if (rs != GC_OK)
+        {
+            gc_stream_cancel_read(s, t);
+            return rs;
+        }
+    rs = gc_stream_end_read(s, st, t);
     if (rs != GC_OK) return rs;
     return acq_fetch(a, host_results, st);
 }

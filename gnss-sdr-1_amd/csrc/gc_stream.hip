@@ -20,8 +20,8 @@ static void stream_release(gc_stream* s)
             if (s->h_slot[i]) (void)hipHostFree(s->h_slot[i]);
             if (s->slot_done[i]) (void)hipEventDestroy(s->slot_done[i]);
         }
-    for (auto& r : s->readers)
-        if (r.done) (void)hipEventDestroy(r.done);
+    for (hipEvent_t e : s->reader_events)
+        if (e) (void)hipEventDestroy(e);
     if (s->pushed) (void)hipEventDestroy(s->pushed);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
 }
@@ -32,40 +32,51 @@ void gc_stream_drop(gc_stream* s)
 {
     if (s->refs.fetch_sub(1) != 1) return;
     gc_device_guard g(s->ctx->device);
-    for (auto& r : s->readers)
-        if (r.active) (void)hipEventSynchronize(r.done);
+    {
+        std::unique_lock<std::mutex> lk(s->mtx);
+        s->readers.drain(lk);
+    }
     stream_release(s);
     delete s;
 }
 
-gc_status gc_stream_begin_read(gc_stream* s, hipStream_t compute)
+gc_status gc_stream_begin_read(gc_stream* s, hipStream_t compute, uint64_t min_index, gc_stream_ticket* t)
 {
-    std::lock_guard<std::mutex> lk(s->mtx);
-    if (s->has_pushed) GC_HIP(hipStreamWaitEvent(compute, s->pushed, 0));
+    std::unique_lock<std::mutex> lk(s->mtx);
+    const int slot = s->readers.reserve(lk, min_index, [s]() { return gc_stream_oldest(s); });
+    if (slot < 0)
+        return gc_fail(GC_ERR_STATE, "the reader fell behind the stream ring: it needs sample %llu, the oldest resident sample is %llu",
+            (unsigned long long)min_index, (unsigned long long)gc_stream_oldest(s));
+    // the range as of the reservation (reserve() returns with the lock held): nothing at or above the floor is evicted from here on
+    t->slot = slot;
+    t->oldest = gc_stream_oldest(s);
+    t->head = s->head;
+    if (s->has_pushed)
+        {
+            hipError_t e = hipStreamWaitEvent(compute, s->pushed, 0);
+            if (e != hipSuccess)
+                {
+                    s->readers.cancel(slot);
+                    t->slot = -1;
+                    return gc_fail(GC_ERR_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+                }
+        }
     return GC_OK;
 }
 
-gc_status gc_stream_end_read(gc_stream* s, hipStream_t compute, uint64_t min_index)
+gc_status gc_stream_end_read(gc_stream* s, hipStream_t compute, const gc_stream_ticket& t)
 {
+    if (t.slot < 0) return GC_OK;
     std::lock_guard<std::mutex> lk(s->mtx);
-    gc_stream::Reader* slot = nullptr;
-    for (auto& r : s->readers)
-        {
-            if (r.active && hipEventQuery(r.done) == hipSuccess) r.active = false;
-            if (!r.active && !slot) slot = &r;
-        }
-    if (!slot)
-        {
-            // every slot is still pending: wait (on the host) for the launch with the oldest floor
-            slot = &s->readers[0];
-            for (auto& r : s->readers)
-                if (r.min_index < slot->min_index) slot = &r;
-            GC_HIP(hipEventSynchronize(slot->done));
-        }
-    slot->min_index = min_index;
-    GC_HIP(hipEventRecord(slot->done, compute));
-    slot->active = true;
+    if (!s->readers.commit(t.slot, compute)) return gc_fail(GC_ERR_HIP, "hipEventRecord failed behind a launch that reads the stream ring");
     return GC_OK;
+}
+
+void gc_stream_cancel_read(gc_stream* s, const gc_stream_ticket& t)
+{
+    if (t.slot < 0) return;
+    std::lock_guard<std::mutex> lk(s->mtx);
+    s->readers.cancel(t.slot);
 }
 
 extern "C" {
@@ -96,9 +107,10 @@ gc_status gc_stream_create(gc_ctx* ctx, int iq_format, uint64_t capacity_samples
             e = hipHostMalloc(reinterpret_cast<void**>(&s->h_slot[i]), s->slot_bytes, hipHostMallocDefault);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->slot_done[i], hipEventDisableTiming);
         }
-    s->readers.assign(8, gc_stream::Reader{0, nullptr, false});
-    for (auto& r : s->readers)
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&r.done, hipEventDisableTiming);
+    s->reader_events.assign(8, nullptr);
+    for (auto& ev : s->reader_events)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) s->readers.init(s->reader_events);
     if (e != hipSuccess)
         {
             stream_release(s);
@@ -150,22 +162,19 @@ static gc_status stream_push(gc_stream* s, const void* host_iq, uint64_t n_sampl
     GC_REQUIRE(s && host_iq, "gc_stream_push: NULL argument");
     GC_REQUIRE(n_samples <= s->capacity, "gc_stream_push: at most capacity = %llu samples per push", (unsigned long long)s->capacity);
     gc_device_guard g(s->ctx->device);
-    std::lock_guard<std::mutex> lk(s->mtx);
+    std::lock_guard<std::mutex> one_push(s->push_mtx);
+    std::unique_lock<std::mutex> lk(s->mtx);
     if (first_index) *first_index = s->head;
     if (n_samples == 0) return GC_OK;
     const uint64_t new_head = s->head + n_samples;
     const uint64_t new_oldest = new_head > s->capacity ? new_head - s->capacity : 0;
-    // kernels that may still read samples this push evicts must finish first
-    // Launches that may still read samples this push evicts must finish first.  The wait is done by the calling
-    // (producer) thread, not by the copy stream: a DMA queue that has to wait for a compute signal takes the
-    // runtime's slow path (measured 316 us instead of 80 us per 3.2 MB push), and blocking here is also the
+    // Launches that may still read samples this push evicts must finish first -- including launches whose reader slot is
+    // reserved but which have not been enqueued yet (gc_reader_table.h).  From here on new readers see the post-push range.
+    // The wait is done by the calling (producer) thread, not by the copy stream: a DMA queue that has to wait for a compute
+    // signal takes the runtime's slow path (measured 316 us instead of 80 us per 3.2 MB push), and blocking here is also the
     // back-pressure that keeps the producer at most one ring ahead of the consumers.
-    for (auto& r : s->readers)
-        if (r.active && r.min_index < new_oldest)
-            {
-                GC_HIP(hipEventSynchronize(r.done));
-                r.active = false;
-            }
+    if (new_oldest > s->evicting_below) s->evicting_below = new_oldest;
+    s->readers.wait_evictable(lk, new_oldest);
     const char* src = static_cast<const char*>(host_iq);
     uint64_t idx = s->head, left = n_samples;
     while (left > 0)

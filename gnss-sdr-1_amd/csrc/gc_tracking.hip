@@ -346,9 +346,11 @@ static std::vector<gc_stream*> batch_streams(const gc_trk_batch* b)
     return v;
 }
 
-// floors: oldest absolute index the launch reads from each ring of batch_streams(b) (NULL: unknown)
+// floors / ends: oldest absolute index the launch reads from each ring of batch_streams(b) and one past the newest (NULL: unknown).
+// The reader slots are reserved BEFORE the residency check and the enqueue, so a push on the producer's thread cannot evict
+// what this launch was validated for (gc_reader_table.h).
 static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_params* dev_params, void* dev_out,
-    hipStream_t st, int max_len, const std::vector<uint64_t>* floors = nullptr)
+    hipStream_t st, int max_len, const std::vector<uint64_t>* floors = nullptr, const std::vector<uint64_t>* ends = nullptr)
 {
     for (int i = 0; i < b->n_channels; i++)
         {
@@ -372,22 +374,38 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
                 }
         }
     const std::vector<gc_stream*> rings = batch_streams(b);
-    for (gc_stream* r : rings)
+    std::vector<gc_stream_ticket> tickets(rings.size());
+    auto cancel_all = [&]() {
+        for (size_t i = 0; i < rings.size(); i++) gc_stream_cancel_read(rings[i], tickets[i]);
+    };
+    for (size_t i = 0; i < rings.size(); i++)
         {
-            gc_status rs = gc_stream_begin_read(r, st);  // the newest push must have landed
-            if (rs != GC_OK) return rs;
+            // later pushes may evict everything below the floor while this launch is still running; the newest push must have landed
+            const uint64_t floor = (floors && (*floors)[i] != ~0ull) ? (*floors)[i] : b->has_read_floor ? b->read_floor : GC_STREAM_FLOOR_OLDEST;
+            gc_status rs = gc_stream_begin_read(rings[i], st, floor, &tickets[i]);
+            if (rs == GC_OK && ends && (*ends)[i] > tickets[i].head)
+                rs = gc_fail(GC_ERR_INVALID, "gc_trk_batch_run: a window ends at sample %llu, the stream's resident samples are [%llu, %llu)",
+                    (unsigned long long)(*ends)[i], (unsigned long long)tickets[i].oldest, (unsigned long long)tickets[i].head);
+            if (rs != GC_OK)
+                {
+                    cancel_all();
+                    return rs;
+                }
         }
     hipError_t e = trk_launch(b->n_taps, b->mode, b->iq_format, st, b->d_chans, dev_params, static_cast<float2*>(dev_out), b->d_partial,
         b->n_channels, n_epochs, n_slices, b->lds_table_floats);
-    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess)
+        {
+            cancel_all();
+            return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
+        }
+    gc_status out = GC_OK;
     for (size_t i = 0; i < rings.size(); i++)
         {
-            // later pushes may evict everything below the floor while this launch is still running
-            const uint64_t floor = floors ? (*floors)[i] : b->has_read_floor ? b->read_floor : gc_stream_oldest(rings[i]);
-            gc_status rs = gc_stream_end_read(rings[i], st, floor);
-            if (rs != GC_OK) return rs;
+            gc_status rs = gc_stream_end_read(rings[i], st, tickets[i]);
+            if (rs != GC_OK) out = rs;
         }
-    return GC_OK;
+    return out;
 }
 
 gc_status gc_trk_batch_run_dev(gc_trk_batch* b, int n_epochs, const gc_epoch_params* dev_params, void* dev_out, void* stream)
@@ -408,7 +426,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
     const size_t jobs = (size_t)b->n_channels * n_epochs;
     int max_len = 0;
     const std::vector<gc_stream*> rings = batch_streams(b);
-    std::vector<uint64_t> floors(rings.size(), ~0ull);
+    std::vector<uint64_t> floors(rings.size(), ~0ull), ends(rings.size(), 0);
     for (size_t j = 0; j < jobs; j++)
         {
             const gc_epoch_params& p = host_params[j];
@@ -425,6 +443,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
                         (unsigned long long)p.sample_offset, p.n_samples, (unsigned long long)oldest, (unsigned long long)head);
                     const size_t ri = std::find(rings.begin(), rings.end(), r) - rings.begin();
                     floors[ri] = std::min(floors[ri], p.sample_offset);
+                    ends[ri] = std::max(ends[ri], p.sample_offset + (uint64_t)p.n_samples);
                 }
             else
                 {
@@ -452,7 +471,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
             b->out_cap = jobs * b->n_taps;
         }
     GC_HIP(hipMemcpyAsync(b->d_params, host_params, jobs * sizeof(gc_epoch_params), hipMemcpyHostToDevice, st));
-    gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len, &floors);
+    gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len, &floors, &ends);
     if (s != GC_OK) return s;
     // 16-bit mode: n_taps lv_16sc_t (4 bytes) per job instead of n_taps complex floats
     const size_t out_elem = b->sc16 ? sizeof(short2) : sizeof(float2);

@@ -752,9 +752,38 @@ struct gc_trk_loop
     std::vector<unsigned long long> pos_host; // last known stream position of the channel (from the records)
     std::vector<char> pos_known;
     std::vector<char> idle;                   // the channel's last record said state 0 (standby after loss of lock)
-    unsigned long long* d_limits = nullptr;
-    unsigned long long* h_limits = nullptr;   // pinned
+    // Per-launch ring limits travel through a small ring of slots (pinned host copy + device copy + an event recorded behind the
+    // launch that reads the device copy): an asynchronous launch keeps its slot until it has finished, so back-to-back
+    // push -> run_dev -> push -> run_dev never rewrites limits an earlier, still queued launch will read.
+    static constexpr int LIMIT_SLOTS = 8;
+    unsigned long long* d_limits[LIMIT_SLOTS] = {};
+    unsigned long long* h_limits[LIMIT_SLOTS] = {};   // pinned
+    hipEvent_t limit_done[LIMIT_SLOTS] = {};
+    bool limit_used[LIMIT_SLOTS] = {};
+    int limit_next = 0;
+    // the last launch of the engine, on whatever stream the caller chose: entry points that rewrite device state wait for it
+    hipEvent_t last_launch = nullptr;
+    bool launched = false;
 };
+
+// waits until no launch of the engine is in flight on any stream (the caller holds the context mutex)
+static hipError_t loop_quiesce(gc_trk_loop* l)
+{
+    hipError_t e = hipStreamSynchronize(l->ctx->stream);
+    if (e == hipSuccess && l->launched) e = hipEventSynchronize(l->last_launch);
+    return e;
+}
+
+static void loop_free_limits(gc_trk_loop* l)
+{
+    for (int k = 0; k < gc_trk_loop::LIMIT_SLOTS; k++)
+        {
+            (void)hipFree(l->d_limits[k]);
+            if (l->h_limits[k]) (void)hipHostFree(l->h_limits[k]);
+            if (l->limit_done[k]) (void)hipEventDestroy(l->limit_done[k]);
+        }
+    if (l->last_launch) (void)hipEventDestroy(l->last_launch);
+}
 
 extern "C" {
 
@@ -794,12 +823,16 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
     l->pos_host.assign(n_channels, 0);
     l->pos_known.assign(n_channels, 0);
     l->idle.assign(n_channels, 0);
-    if (hipMalloc(&l->d_limits, sizeof(unsigned long long) * n_channels) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&l->h_limits), sizeof(unsigned long long) * n_channels, hipHostMallocDefault) != hipSuccess)
+    bool ok = hipEventCreateWithFlags(&l->last_launch, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < gc_trk_loop::LIMIT_SLOTS && ok; k++)
+        ok = hipMalloc(&l->d_limits[k], sizeof(unsigned long long) * n_channels) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void**>(&l->h_limits[k]), sizeof(unsigned long long) * n_channels, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&l->limit_done[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok)
         {
+            loop_free_limits(l);
             (void)hipFree(l->d_chans);
             (void)hipFree(l->d_codes);
-            (void)hipFree(l->d_limits);
             delete l;
             return gc_fail(GC_ERR_HIP, "gc_trk_loop_create: allocation failed");
         }
@@ -811,13 +844,12 @@ gc_status gc_trk_loop_destroy(gc_trk_loop* l)
 {
     if (!l) return GC_OK;
     gc_device_guard g(l->ctx->device);
-    (void)hipStreamSynchronize(l->ctx->stream);
+    (void)loop_quiesce(l);
     (void)hipFree(l->d_chans);
     (void)hipFree(l->d_codes);
     (void)hipFree(l->d_data_codes);
     (void)hipFree(l->d_recs);
-    (void)hipFree(l->d_limits);
-    if (l->h_limits) (void)hipHostFree(l->h_limits);
+    loop_free_limits(l);
     for (gc_stream* r : l->streams)
         if (r) gc_stream_drop(r);
     delete l;
@@ -839,7 +871,7 @@ gc_status gc_trk_loop_set_input_dev(gc_trk_loop* l, int ch, const void* dev_iq, 
     if (l->started[ch])
         {
             // a running channel keeps its state; only the input block changes (stream position restarts at 0)
-            GC_HIP(hipStreamSynchronize(l->ctx->stream));
+            GC_HIP(loop_quiesce(l));
             LoopChan h;
             GC_HIP(hipMemcpy(&h, l->d_chans + ch, sizeof h, hipMemcpyDeviceToHost));
             h.chan.iq = dev_iq;
@@ -929,7 +961,7 @@ gc_status gc_trk_loop_set_sync(gc_trk_loop* l, int ch, const gc_loop_sync_conf* 
             GC_REQUIRE(data_code_length > 0 && data_code_length <= l->max_code_len, "gc_trk_loop_set_sync: data_code_length %d not in 1..%d", data_code_length,
                 l->max_code_len);
             if (!l->d_data_codes) GC_HIP(hipMalloc(&l->d_data_codes, sizeof(float) * (size_t)l->n_channels * l->max_code_len));
-            GC_HIP(hipStreamSynchronize(l->ctx->stream));
+            GC_HIP(loop_quiesce(l));
             GC_HIP(hipMemcpy(l->d_data_codes + (size_t)ch * l->max_code_len, data_code, sizeof(float) * data_code_length, hipMemcpyHostToDevice));
             l->data_code_len[ch] = data_code_length;  // must equal the tracking replica's length: checked at start
         }
@@ -949,10 +981,14 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
         "gc_trk_loop_start: code_length %d != code_length_chips * code_samples_per_chip", code_length);
     GC_REQUIRE(conf->high_dyn_smoother_length <= LOOP_MAX_SMOOTHER, "gc_trk_loop_start: high_dyn_smoother_length must be <= %d", LOOP_MAX_SMOOTHER);
     const int n_taps = conf->veml ? 5 : 3;
-    if (l->n_taps == 0) l->n_taps = n_taps;
-    GC_REQUIRE(l->n_taps == n_taps, "gc_trk_loop_start: all channels of one loop engine use the same tap count (%d)", l->n_taps);
     gc_device_guard g(l->ctx->device);
     std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    {
+        // the engine's tap count is that of its running channels: it is free again once every channel has been stopped
+        bool any_started = false;
+        for (int i = 0; i < l->n_channels; i++) any_started |= (i != ch && l->started[i]);
+        GC_REQUIRE(!any_started || l->n_taps == n_taps, "gc_trk_loop_start: all channels of one loop engine use the same tap count (%d)", l->n_taps);
+    }
     LoopSync y = l->sync[ch];
     if (y.extend_symbols == 0)
         {
@@ -978,7 +1014,8 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
     GC_REQUIRE(l->high_dyn == hd, "gc_trk_loop_start: all channels of one loop engine share the high_dyn mode (%d)", l->high_dyn);
 
     hipStream_t st = l->ctx->stream;
-    GC_HIP(hipStreamSynchronize(st));
+    GC_HIP(loop_quiesce(l));
+    l->n_taps = n_taps;  // every check has passed
     GC_HIP(hipMemcpy(l->d_codes + (size_t)ch * l->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
     LoopChan h;
     std::memset(&h, 0, sizeof h);
@@ -1034,7 +1071,7 @@ extern "C" gc_status gc_trk_loop_stop(gc_trk_loop* l, int ch)
     gc_device_guard g(l->ctx->device);
     std::lock_guard<std::mutex> lk(l->ctx->mtx);
     if (!l->started[ch]) return GC_OK;
-    GC_HIP(hipStreamSynchronize(l->ctx->stream));
+    GC_HIP(loop_quiesce(l));
     // n_taps = 0 marks the slot as standby for the kernel; the rest of the state is rewritten by the next start
     int zero = 0;
     GC_HIP(hipMemcpy(reinterpret_cast<char*>(l->d_chans + ch) + offsetof(LoopChan, n_taps), &zero, sizeof zero, hipMemcpyHostToDevice));
@@ -1052,47 +1089,76 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
         for (int i = 0; i < l->n_channels; i++) any |= l->started[i] != 0;
         if (!any) return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: no channel has been started (gc_trk_loop_start)");
     }
-    // ring inputs: this launch may use what has been pushed so far, and must not be overtaken by later pushes
+    // ring inputs: this launch may use what has been pushed so far, and must not be overtaken by later pushes.  Reader slots
+    // are reserved (floor = the oldest sample a channel with a known position still needs, else the oldest resident one) before
+    // the residency check and the enqueue; the limits are the heads seen by those reservations.
     std::vector<gc_stream*> rings;
     std::vector<uint64_t> floors;
+    std::vector<char> floor_unknown;
+    std::vector<gc_stream_ticket> tickets;
     bool any_ring = false;
+    // this launch's slot of the limits ring: free once the launch that used it last has finished
+    const int slot = l->limit_next;
+    if (l->limit_used[slot]) GC_HIP(hipEventSynchronize(l->limit_done[slot]));
+    unsigned long long* h_limits = l->h_limits[slot];
     for (int i = 0; i < l->n_channels; i++)
         {
             gc_stream* r = l->streams[i];
-            l->h_limits[i] = l->n_iq[i];
+            h_limits[i] = l->n_iq[i];
             if (!r) continue;
             any_ring = true;
-            if (!l->started[i] || l->idle[i])
-                {
-                    // standby (never started, stopped, or lost lock): reads nothing, holds nothing back in the ring
-                    l->h_limits[i] = 0;
-                    continue;
-                }
-            uint64_t oldest = 0, head = 0;
-            gc_stream_info(r, &oldest, &head, nullptr);
-            l->h_limits[i] = head;
+            // standby (never started, stopped, or lost lock): reads nothing, holds nothing back in the ring
+            if (!l->started[i] || l->idle[i]) continue;
             const bool known = positions_known && l->pos_known[i];
-            if (known && l->pos_host[i] < oldest)
-                return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: channel %d (at sample %llu) fell behind the ring (oldest resident sample %llu)", i,
-                    (unsigned long long)l->pos_host[i], (unsigned long long)oldest);
             size_t k = std::find(rings.begin(), rings.end(), r) - rings.begin();
             if (k == rings.size())
                 {
                     rings.push_back(r);
                     floors.push_back(~0ull);
+                    floor_unknown.push_back(0);
                 }
-            floors[k] = std::min<uint64_t>(floors[k], known ? l->pos_host[i] : oldest);
+            // one channel with an unknown position pins the floor at the oldest resident sample
+            if (!known) floor_unknown[k] = 1;
+            floors[k] = std::min<uint64_t>(floors[k], known ? l->pos_host[i] : ~0ull);
+        }
+    auto cancel_all = [&]() {
+        for (size_t k = 0; k < tickets.size(); k++) gc_stream_cancel_read(rings[k], tickets[k]);
+    };
+    tickets.resize(rings.size());
+    for (size_t k = 0; k < rings.size(); k++)
+        {
+            const bool pinned_oldest = floor_unknown[k] || floors[k] == ~0ull;
+            gc_status rs = gc_stream_begin_read(rings[k], st, pinned_oldest ? GC_STREAM_FLOOR_OLDEST : floors[k], &tickets[k]);
+            if (rs != GC_OK)
+                {
+                    cancel_all();
+                    if (!pinned_oldest)
+                        return gc_fail(GC_ERR_STATE, "gc_trk_loop_run: a channel (at sample %llu) fell behind the ring", (unsigned long long)floors[k]);
+                    return rs;
+                }
+        }
+    for (int i = 0; i < l->n_channels; i++)
+        {
+            gc_stream* r = l->streams[i];
+            if (!r) continue;
+            if (!l->started[i] || l->idle[i])
+                {
+                    h_limits[i] = 0;
+                    continue;
+                }
+            const size_t k = std::find(rings.begin(), rings.end(), r) - rings.begin();
+            h_limits[i] = tickets[k].head;
         }
     if (any_ring)
         {
-            for (gc_stream* r : rings)
+            hipError_t ce = hipMemcpyAsync(l->d_limits[slot], h_limits, sizeof(unsigned long long) * l->n_channels, hipMemcpyHostToDevice, st);
+            if (ce != hipSuccess)
                 {
-                    gc_status rs = gc_stream_begin_read(r, st);
-                    if (rs != GC_OK) return rs;
+                    cancel_all();
+                    return gc_fail(GC_ERR_HIP, "gc_trk_loop_run: %s", hipGetErrorString(ce));
                 }
-            GC_HIP(hipMemcpyAsync(l->d_limits, l->h_limits, sizeof(unsigned long long) * l->n_channels, hipMemcpyHostToDevice, st));
         }
-    const unsigned long long* limits = any_ring ? l->d_limits : nullptr;
+    const unsigned long long* limits = any_ring ? l->d_limits[slot] : nullptr;
     const bool pilot = l->pilot > 0;
     const int lds_table_floats = (l->max_code_len + 64) * (pilot ? 2 : 1);
     // few channels: more threads each, so that a channel's epoch is spread over a whole CU (measured, 256 channels x 64
@@ -1176,13 +1242,29 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
 #undef LAUNCH_LOOP_FMT
 #undef LAUNCH_LOOP
 #undef LAUNCH_LOOP_D
-    GC_HIP(hipGetLastError());
+    {
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+            {
+                cancel_all();
+                return gc_fail(GC_ERR_HIP, "gc_trk_loop_run: kernel launch failed: %s", hipGetErrorString(le));
+            }
+    }
+    GC_HIP(hipEventRecord(l->last_launch, st));
+    l->launched = true;
+    if (any_ring)
+        {
+            GC_HIP(hipEventRecord(l->limit_done[slot], st));
+            l->limit_used[slot] = true;
+            l->limit_next = (slot + 1) % gc_trk_loop::LIMIT_SLOTS;
+        }
+    gc_status out = GC_OK;
     for (size_t k = 0; k < rings.size(); k++)
         {
-            gc_status rs = gc_stream_end_read(rings[k], st, floors[k]);
-            if (rs != GC_OK) return rs;
+            gc_status rs = gc_stream_end_read(rings[k], st, tickets[k]);
+            if (rs != GC_OK) out = rs;
         }
-    return GC_OK;
+    return out;
 }
 
 gc_status gc_trk_loop_run_dev(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, void* stream)

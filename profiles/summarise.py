@@ -1,7 +1,8 @@
 """Turns the raw rocprofv3 output of profiles/collect.sh (gpurun_out/prof_*) into the small files committed under
 profiles/: per-kernel duration tables and traffic_latest.json (HBM bytes per launch of the tracking kernel, with the
 gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section: the counter reports 64 B per 128-B request of a
-16-B/lane streaming load, so it is doubled; WRITE_SIZE is exact).  Usage: python profiles/summarise.py [round_tag]"""
+16-B/lane streaming load, so it is doubled; WRITE_SIZE is exact).  The acquisition passes give acq_latest.json: HBM bytes per cfg4 search over every acq_* kernel, per-kernel durations and the SQ
+counters of the dominant kernels.  Usage: python profiles/summarise.py [round_tag] [full trk acq sq]"""
 import csv
 import json
 import os
@@ -11,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+PASSES = sys.argv[2:] or ["full", "trk", "acq", "sq"]
 KERNEL = "trk_multicorrelator_kernel<3, false, false, 0, false, false>"
 
 
@@ -23,13 +25,100 @@ def counter_mean(path, counter):
     return sum(vals) / len(vals), len(vals)
 
 
+def find(d, suffix):
+    """rocprofv3 nests its output under <dir>/<host>/...: first file below d that ends with suffix"""
+    for root, _, files in os.walk(os.path.join(OUT, d)):
+        for f in sorted(files):
+            if f.endswith(suffix):
+                return os.path.join(root, f)
+    raise FileNotFoundError((d, suffix))
+
+
+def short(name):
+    name = name[5:] if name.startswith("void ") else name
+    return name.split("(")[0]
+
+
+def acq_summary():
+    """acq_* kernels of the cfg4 search: durations (stats pass), HBM bytes (FETCH x 2 + WRITE) and SQ counters, per search."""
+    stats_path = find("prof_acq", "kernel_stats.csv")
+    shutil.copy(stats_path, os.path.join(PROF, TAG + "_acq_kernel_stats.csv"))
+    searches_stats = 1 + 9   # collect.sh: 1 warm-up + --acq-reps 9
+    searches_pmc = 1 + 4
+    kern = {}
+    for r in csv.DictReader(open(stats_path)):
+        n = short(r["Name"])
+        if n.startswith("acq_"):
+            kern[n] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+    def counter_sums(d, counters):
+        sums = {}
+        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+            n = short(r["Kernel_Name"])
+            if n.startswith("acq_") and r["Counter_Name"] in counters:
+                sums.setdefault(n, {}).setdefault(r["Counter_Name"], [0.0, 0])
+                sums[n][r["Counter_Name"]][0] += float(r["Counter_Value"])
+                sums[n][r["Counter_Name"]][1] += 1
+        return sums
+    fetch = counter_sums("prof_acq_fetch", {"FETCH_SIZE"})
+    write = counter_sums("prof_acq_write", {"WRITE_SIZE"})
+    total_fetch_kb = sum(v["FETCH_SIZE"][0] for v in fetch.values())
+    total_write_kb = sum(v["WRITE_SIZE"][0] for v in write.values())
+    per_kernel = {}
+    for n in sorted(kern):
+        f = fetch.get(n, {}).get("FETCH_SIZE", [0.0, 1])
+        w = write.get(n, {}).get("WRITE_SIZE", [0.0, 1])
+        per_kernel[n] = dict(kern[n], ms_per_search=kern[n]["total_ms"] / searches_stats,
+            fetch_kb_per_launch=f[0] / max(1, f[1]), write_kb_per_launch=w[0] / max(1, w[1]),
+            hbm_mb_per_search=(2.0 * f[0] + w[0]) * 1024.0 / searches_pmc / 1e6)
+    dom = max(kern, key=lambda n: kern[n]["total_ms"])
+    alg = 32 * 41 * 25000 * (20 + 24)
+    out = {"round": int(TAG[1:]), "workload": "bench.py acquisition: GPS L1 C/A PCPS, 25 Msps, N = 25000, 32 PRNs x 41 bins x 2 dwells",
+        "searches_in_stats_pass": searches_stats, "searches_in_pmc_passes": searches_pmc,
+        "correction": "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section), WRITE_SIZE exact; the 32 set_local_code transforms of the set-up "
+                      "run the same kernels on one cell each and are included (< 1 %)",
+        "hbm_bytes_per_search": (2.0 * total_fetch_kb + total_write_kb) * 1024.0 / searches_pmc,
+        "algorithmic_bytes_per_search": alg, "dominant_kernel": dom, "dominant_kernel_us": kern[dom]["avg_us"],
+        "kernel_ms_per_search": sum(k["total_ms"] for k in kern.values()) / searches_stats, "kernels": per_kernel}
+    out["traffic_over_algorithmic"] = out["hbm_bytes_per_search"] / alg
+    if "sq" in PASSES:
+        sq = {}
+        for d in ("prof_acq_sq1", "prof_acq_sq2"):
+            try:
+                path = find(d, "counter_collection.csv")
+            except FileNotFoundError:
+                continue
+            for r in csv.DictReader(open(path)):
+                n = short(r["Kernel_Name"])
+                if n.startswith("acq_"):
+                    e = sq.setdefault(n, {}).setdefault(r["Counter_Name"], [0.0, 0])
+                    e[0] += float(r["Counter_Value"])
+                    e[1] += 1
+        out["sq_counters_mean_per_launch"] = {n: {c: v[0] / v[1] for c, v in sorted(cs.items())} for n, cs in sorted(sq.items())}
+    json.dump(out, open(os.path.join(PROF, "acq_latest.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(PROF, TAG + "_acq_summary.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k not in ("kernels", "sq_counters_mean_per_launch")}, indent=1))
+    for n, k in per_kernel.items():
+        print("%-60s %5d calls %8.1f us  %7.3f ms/search  %8.1f MB/search" % (n[:60], k["calls"], k["avg_us"], k["ms_per_search"], k["hbm_mb_per_search"]))
+
+
 def main():
-    shutil.copy(os.path.join(OUT, "prof_full", "full_kernel_stats.csv"), os.path.join(PROF, TAG + "_full_bench_kernel_stats.csv"))
-    shutil.copy(os.path.join(OUT, "prof_trk", "trk_kernel_stats.csv"), os.path.join(PROF, TAG + "_tracking_kernel_stats.csv"))
-    fetch, nf = counter_mean(os.path.join(OUT, "prof_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
-    write, nw = counter_mean(os.path.join(OUT, "prof_write", "write_counter_collection.csv"), "WRITE_SIZE")
-    for name, src in (("fetch", "prof_fetch/fetch_counter_collection.csv"), ("write", "prof_write/write_counter_collection.csv")):
-        rows = [r for r in csv.DictReader(open(os.path.join(OUT, src))) if r["Kernel_Name"].startswith("void " + KERNEL)]
+    if "acq" in PASSES:
+        acq_summary()
+    if "full" in PASSES:
+        shutil.copy(find("prof_full", "kernel_stats.csv"), os.path.join(PROF, TAG + "_full_bench_kernel_stats.csv"))
+        for line in open(os.path.join(OUT, "prof_full.log")):
+            if line.startswith("{"):
+                open(os.path.join(PROF, TAG + "_bench_line_under_rocprof.json"), "w").write(line)
+    if "trk" in PASSES:
+        trk_summary()
+
+
+def trk_summary():
+    shutil.copy(find("prof_trk", "kernel_stats.csv"), os.path.join(PROF, TAG + "_tracking_kernel_stats.csv"))
+    fetch, nf = counter_mean(find("prof_fetch", "counter_collection.csv"), "FETCH_SIZE")
+    write, nw = counter_mean(find("prof_write", "counter_collection.csv"), "WRITE_SIZE")
+    for name, src in (("fetch", find("prof_fetch", "counter_collection.csv")), ("write", find("prof_write", "counter_collection.csv"))):
+        rows = [r for r in csv.DictReader(open(src)) if r["Kernel_Name"].startswith("void " + KERNEL)]
         with open(os.path.join(PROF, "%s_tracking_%s_size.csv" % (TAG, name)), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
             w.writeheader()
@@ -47,9 +136,6 @@ def main():
     }
     json.dump(traffic, open(os.path.join(PROF, "traffic_latest.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
-    for line in open(os.path.join(OUT, "prof_full.log")):
-        if line.startswith("{"):
-            open(os.path.join(PROF, TAG + "_bench_line_under_rocprof.json"), "w").write(line)
 
 
 if __name__ == "__main__":

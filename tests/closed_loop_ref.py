@@ -249,6 +249,7 @@ def run(oracle, x, code, conf, n_epochs, sync=None, data_code=None):
         args = (f32(rem_carr), f32(step), f32(f32(rem_code_chips) * f32(spc)), f32(f32(code_step) * f32(spc)), N)
         if sl:
             args = args + (f32(hd["carr_rate"]), f32(f32(hd["code_rate"]) * f32(spc)), True)
+        pos_in, shifts_in = pos, shifts.copy()
         corr = oracle.multicorrelator(x[pos:], code, shifts, *args)
         pdata = oracle.multicorrelator(x[pos:], data_code, shifts[len(shifts) // 2:len(shifts) // 2 + 1], *args)[0] if pilot else corr[len(shifts) // 2]
         P = corr[len(shifts) // 2]
@@ -321,5 +322,5 @@ def run(oracle, x, code, conf, n_epochs, sync=None, data_code=None):
         pos += cur
         out.append(dict(corr=corr, doppler=doppler, code_freq=code_freq, cur=cur, sample_counter=sample_counter, cn0=st["cn0"], lock_test=st["lock_test"],
             perr=st["perr"], cerr=st["cerr"], rem_code_samples=rem_code_samples, acc_phase=acc_phase, state=st["state"], state_in=state_in, valid=valid,
-            integrating=integrating, accu=log_accu, ext_count=log_count, prompt_data=pdata))
+            integrating=integrating, accu=log_accu, ext_count=log_count, prompt_data=pdata, args=args, pos=pos_in, shifts=shifts_in))
     return out

@@ -330,3 +330,91 @@ def test_galileo_e1_real_capture_batched(gctx, oracle):
         assert r.indext == a["delay_samples"] and abs(r.doppler_hz) == a["abs_doppler_hz"]
     assert min(res[0].test_statistics, res[1].test_statistics) > 2.0 * max(res[2].test_statistics, res[3].test_statistics)
     acq.close()
+
+
+def test_cfg4_full_width_32_prns_41_bins_2_dwells(gctx, oracle):
+    """BASELINE configs[3] at full width, through the path bench.py times (dwell_enqueue x 2 + fetch_results on a caller stream):
+    GPS L1 C/A, 25 Msps, N = 25000, 32 PRNs x 41 Doppler bins x 2 non-coherent dwells; PRN 1-16 present at C/N0 in [38, 48] dB-Hz,
+    PRN 17-32 absent, CFAR off because max_dwells = 2 (pcps_acquisition.cc:152-159).  41 bins come from the
+    reference's own formula with doppler_max = 5125 (ceil(10250 / 250), :326), so the oracle searches the same grid.  With the
+    default 140 MB inter-pass buffer the 32 satellites run as 16 + 16 (gc_acquisition.hip); every satellite of both batches is
+    checked against the oracle's acquisition_core (:668-770) after EACH dwell: peak cell exact, magnitudes and statistics <= 1e-4."""
+    import gnsscorr
+    import torch
+    from helpers import synth_stream
+    fs, n = 25_000_000, 25000
+    prns = list(range(1, 33))
+    chips = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in prns[:16]]
+    x, truth = synth_stream(chips, fs, 2 * n, seed=1004, cn0_db_hz=(38.0, 48.0))
+    c = _conf(fs, 1, 1, 25000.0, 5125, 250, max_dwells=2)
+    acq = gnsscorr.PcpsAcquisition(gctx, 32, **c)
+    assert (acq.fft_size, acq.num_doppler_bins) == (25000, 41)
+    orcs = []
+    for s, prn in enumerate(prns):
+        code = oracle.gps_l1_ca_code_sampled(prn, fs)
+        acq.set_local_code(s, code)
+        p = oracle.pcps(**c)
+        p.set_local_code(code)
+        orcs.append(p)
+    d_x = torch.from_numpy(x.view(np.float32)).cuda()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    per_dwell = []
+    for rep in range(2):  # the second search, after reset(), must store over the first one's grid (no memset in between)
+        acq.reset()
+        for d in range(2):
+            acq.dwell_enqueue(d_x.data_ptr() + 8 * n * d, st.cuda_stream)
+            if rep == 0:
+                per_dwell.append(acq.fetch_results(st.cuda_stream))
+        last = acq.fetch_results(st.cuda_stream)
+    for s in range(32):
+        orcs[s].reset_grid()
+        for d in range(2):
+            q = orcs[s].core(x[d * n:])
+            _check(per_dwell[d][s], q, cfar=False)
+            assert per_dwell[d][s].second_peak == pytest.approx(q.second_peak, rel=TOL)
+        _check(last[s], q, cfar=False)
+    # a satellite of each batch, whole grid
+    for s in (3, 29):
+        ref = orcs[s].grid()
+        assert np.max(np.abs(acq.grid(s) - ref)) <= TOL * ref.max()
+    # the strong half of the present satellites is found where the truth puts it; nothing absent beats them
+    stats = np.array([r.test_statistics for r in last])
+    strong = [s for s in range(16) if truth[s]["cn0"] >= 44.0]
+    assert len(strong) >= 4
+    for s in strong:
+        expect = (-truth[s]["tau0"] * fs / 1.023e6) % n
+        assert min(abs(last[s].indext - expect), n - abs(last[s].indext - expect)) <= 25 and abs(last[s].doppler_hz - truth[s]["doppler"]) <= 250
+    assert min(stats[strong]) > max(stats[16:])
+    acq.close()
+
+
+def test_uneven_satellite_batches(gctx, oracle, monkeypatch):
+    """The inter-pass buffer forced down to 1 MB (GNSSCORR_ACQ_Q_MB, read when the engine is created): 7 satellites x 10 bins at
+    N = 4000 (320 KB per satellite) run as 3 + 3 + 1 -- the ragged last batch -- and 2 dwells accumulate across them."""
+    import gnsscorr
+    from helpers import synth_stream
+    monkeypatch.setenv("GNSSCORR_ACQ_Q_MB", "1")
+    fs, n = 4_000_000, 4000
+    prns = [2, 5, 9, 14, 21, 27, 30]
+    chips = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in prns[:4]]
+    x, truth = synth_stream(chips, fs, 2 * n, seed=77, cn0_db_hz=(44.0, 50.0), doppler_max=2000.0)
+    c = _conf(fs, 1, 1, 4000.0, 2500, 500, max_dwells=2)
+    acq = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
+    assert acq.num_doppler_bins == 10
+    orcs = []
+    for s, prn in enumerate(prns):
+        code = oracle.gps_l1_ca_code_sampled(prn, fs)
+        acq.set_local_code(s, code)
+        p = oracle.pcps(**c)
+        p.set_local_code(code)
+        orcs.append(p)
+    for d in range(2):
+        res = acq.dwell(x[d * n:])
+        for s in range(len(prns)):
+            _check(res[s], orcs[s].core(x[d * n:]), cfar=False)
+    for s in range(len(prns)):
+        ref = orcs[s].grid()
+        assert np.max(np.abs(acq.grid(s) - ref)) <= TOL * ref.max()
+    assert min(r.test_statistics for r in res[:4]) > max(r.test_statistics for r in res[4:])
+    acq.close()

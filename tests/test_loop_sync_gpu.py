@@ -48,6 +48,21 @@ def _stream(components, fs, n, doppler, delay, cn0, seed, chip_rate_samples, car
     return x.astype(np.complex64)
 
 
+def _discriminators(accu, veml):
+    """run_dll_pll's discriminators (dll_pll_veml_tracking.cc:914-973, tracking_discriminators.cc:41-128) on accumulators
+    VE E P L VL: (code error, (two-quadrant, four-quadrant) carrier phase error in cycles)."""
+    a = np.asarray(accu, np.complex128)
+    if veml:
+        pe, pl = np.sqrt(abs(a[0]) ** 2 + abs(a[1]) ** 2), np.sqrt(abs(a[4]) ** 2 + abs(a[3]) ** 2)
+        cerr = 0.0 if pe + pl == 0 else (pe - pl) / (pe + pl)
+    else:
+        pe, pl = abs(a[1]), abs(a[3])
+        cerr = 0.0 if pe + pl == 0 else 0.5 * (pe - pl) / (pe + pl)
+    P = a[2]
+    two = (np.arctan(P.imag / P.real) if P.real != 0 else 0.0) / (2 * np.pi)
+    return float(cerr), (float(two), float(np.arctan2(P.imag, P.real) / (2 * np.pi)))
+
+
 def _compare(rec, ref, n_taps, tol=3e-3, abs_tol=0.0):
     """abs_tol: what one sample on the other side of a chip edge may change in a tap sum (2 |x|).  The device computes the
     NCO scalars with its own double-precision libm; a last-bit difference in one of them, rounded to float, moves a chip edge
@@ -68,7 +83,15 @@ def _compare(rec, ref, n_taps, tol=3e-3, abs_tol=0.0):
         assert np.max(np.abs(ga - r["accu"])) <= max(tol * max(scale, np.max(np.abs(r["accu"]))), 4 * abs_tol), k
         loose = abs_tol / scale  # relative size of one sample in a tap (0 for the fixed scenarios)
         assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.05 + 40 * loose, k
-        # the discriminator divides by |E| + |L|: a chip-edge sample weighs 1 / that sum, which is small when the loop is far off
+        if int(g["valid"]) and not int(g["integrating"]):
+            # The loop maths on its own, independent of chip-edge events in the correlator: the discriminators of run_dll_pll
+            # (:914-973) evaluated on the DEVICE's accumulators must give the device's own outputs.  Tight, and it holds in
+            # states 2 and 4 alike (test_seed_4242_group_43_is_a_chip_edge_event has the numbers behind the gate below).
+            cerr_own, perr_own = _discriminators(ga, n_taps == 5)
+            assert abs(float(g["code_error_chips"]) - cerr_own) < 2e-5, (k, float(g["code_error_chips"]), cerr_own)
+            assert min(abs(float(g["carr_phase_error_hz"]) - p) for p in perr_own) < 2e-6, (k, float(g["carr_phase_error_hz"]), perr_own)
+        # cerr = (pe - pl) / (pe + pl): d cerr / d pe = 2 pl / (pe + pl)^2 <= 2 / (pe + pl), so accumulators that differ by
+        # abs_tol (a chip-edge sample) move it by at most 2 abs_tol / (|E| + |L|) -- large when the loop is far off the peak
         el = float(np.sum(np.abs(r["accu"][[1, 3]]))) if r["accu"] is not None else scale
         assert abs(float(g["code_error_chips"]) - r["cerr"]) < 3e-3 + 2 * loose + 2 * abs_tol / max(el, 1e-9), k
         assert abs(float(g["cn0_db_hz"]) - r["cn0"]) < 0.05 + 40 * loose and abs(float(g["carrier_lock_test"]) - r["lock_test"]) < 2e-3 + 2 * loose, k

@@ -256,3 +256,50 @@ def test_broadcast_of_one_pinned_block_into_several_rings(gctx, oracle):
         gnsscorr.stream_broadcast_pinned([rings[0], other], host.data_ptr(), 16)
     for r in rings:
         r.close()
+
+
+def test_closed_loop_push_run_dev_back_to_back_without_sync(gctx, oracle):
+    """push -> run_dev -> push -> run_dev ... with NO host synchronisation in between, the launches queued behind a slow kernel on
+    the caller's stream so that several are pending at once: every launch must see the ring head of ITS OWN push (the limits
+    travel through a ring of slots, one per pending launch), not the head of a later one whose DMA may not have landed.  The valid
+    records, in order, equal those of the same capture tracked as one block with run()."""
+    import gnsscorr
+    import torch
+    from test_closed_loop_gpu import GPS, _conf, _signal
+    fs, n_ep = 4e6, 48
+    code, x = _signal(oracle, 9, fs, 4000 * (n_ep + 3), 55, -2210.0, 777.0)
+    conf = dict(GPS, acq_delay_samples=777.0, acq_doppler_hz=-2200.0, acq_samplestamp_samples=0, sample_counter=0)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    lin = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    lin.set_input_dev(0, d.data_ptr(), x.size)
+    lin.start(0, _conf(gnsscorr, **conf), code)
+    want = lin.run(n_ep)[0]
+    lin.close()
+
+    # a ring large enough for the whole capture: nothing is evicted, so the only thing at stake is which head a launch sees
+    ring = gnsscorr.IqStream(gctx, capacity_samples=4000 * (n_ep + 8), max_window_samples=4000)
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_stream(0, ring)
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    st = torch.cuda.Stream()
+    per_launch = 3
+    blocks = [(p, min(6500, x.size - p)) for p in range(0, x.size, 6500)]
+    item = gnsscorr.LOOP_RECORD_DTYPE.itemsize
+    d_rec = torch.zeros(len(blocks) * per_launch * item, dtype=torch.uint8, device="cuda")
+    pinned = torch.from_numpy(x.view(np.float32).copy()).pin_memory()
+    busy = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        for _ in range(6):
+            busy = busy @ busy * 1e-3   # ~ms of queued work in front of the loop launches: they pile up behind it
+    for k, (p, m) in enumerate(blocks):
+        ring.push_pinned(pinned.data_ptr() + 8 * p, m)
+        loop.run_dev(per_launch, d_rec.data_ptr() + k * per_launch * item, st.cuda_stream)
+    torch.cuda.synchronize()
+    rec = np.frombuffer(d_rec.cpu().numpy().tobytes(), gnsscorr.LOOP_RECORD_DTYPE)
+    got = rec[rec["valid"] == 1][:n_ep]
+    assert len(got) == n_ep
+    for name in want.dtype.names:
+        assert np.array_equal(got[name], want[name]), name
+    loop.close()
+    ring.close()

@@ -288,3 +288,80 @@ def test_parameter_extremes(gctx, oracle, case):
     ref = oracle.multicorrelator(sig[3:], code, shifts, np.float32(0.7), carr, rem, step, n)
     got = _batch_one(gctx, sig, code, shifts, rec)[0]
     assert np.max(np.abs(got - ref)) <= 2e-5 * np.sqrt(n) + TOL * np.max(np.abs(ref)), (case, got, ref)
+
+
+def _run_group(gctx, d_sig, n_sig, codes, shifts, truths, fs, L, n, n_ep):
+    """One batched launch: channel ch tracks codes[ch] on the shared device stream with open-loop records from its truth."""
+    import gnsscorr
+    params = [[gnsscorr.epoch_params(p["sample_offset"], float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), float(p["code_step"]), n)
+        for p in open_loop_params(truths[ch], fs, L, n, n_ep)] for ch in range(len(codes))]
+    b = gnsscorr.TrackingBatch(gctx, len(codes), len(shifts), L)
+    for ch, code in enumerate(codes):
+        b.set_code(ch, code, shifts)
+        b.set_input_dev(ch, d_sig.data_ptr(), n_sig)
+    out = b.run(n_ep, gnsscorr.epoch_params_array(params))
+    b.close()
+    return out
+
+
+def test_full_size_properties_cfg3_galileo_32_channels(gctx, oracle):
+    """BASELINE configs[2] at full width: Galileo E1 sinBOC(1,1) replicas (L = 8184, 2 samples per chip), 32 channels, 25 Msps,
+    5 taps VE/E/P/L/VL at -+0.6 / -+0.15 chips, N = 100000 (4 ms coherent), 6 periods, all channels on one RF stream
+    (gnss_flowgraph.cc:496-499).  Exact linearity in the input, every prompt sees its signal, and 8 random channel-periods
+    against the oracle at 1e-4 of the prompt."""
+    import torch
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    fs, n, n_ch, n_ep = 25_000_000, 100000, 32, 6
+    codes = [oracle.galileo_e1_sinboc11(e1b[prn]) for prn in range(n_ch)]
+    sig, truth = synth_stream(codes, fs, n * n_ep + 8, seed=1003, cn0_db_hz=(40.0, 48.0), chip_rate=2 * 1.023e6)
+    shifts = np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32)
+    d1 = torch.from_numpy(sig.view(np.float32)).cuda()
+    d2 = (d1 * 2.0).contiguous()
+    outs = [_run_group(gctx, d, sig.size, codes, shifts, truth, fs, 8184, n, n_ep) for d in (d1, d2)]
+    assert np.array_equal(outs[1], outs[0] * 2)
+    pm = np.abs(outs[0][:, :, 2])
+    for ch in range(n_ch):
+        assert pm[ch].mean() > 0.6 * truth[ch]["amp"] * n
+        # E and L on the main lobe of the BOC autocorrelation, VE / VL on the far side of its zero crossing
+        assert np.abs(outs[0][ch, :, 1]).mean() > np.abs(outs[0][ch, :, 0]).mean()
+    rng = np.random.Generator(np.random.PCG64(6))
+    for _ in range(8):
+        ch, k = int(rng.integers(n_ch)), int(rng.integers(n_ep))
+        p = open_loop_params(truth[ch], fs, 8184, n, n_ep)[k]
+        ref = oracle.multicorrelator(sig[p["sample_offset"]:], codes[ch], shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
+        assert rel_err(outs[0][ch, k], ref, 2) <= TOL
+
+
+def test_cfg5_per_gpu_mix_gps_galileo_beidou(gctx, oracle):
+    """One GPU's share of BASELINE configs[4] (256 channels round-robin over 8 GPUs = 32 per GPU): 16 GPS L1 C/A (3 taps,
+    L = 1023) + 8 Galileo E1 (5 taps, L = 8184, 4 ms) on the L1 stream and 8 BeiDou B1I (3 taps, L = 2046) on the B1 stream
+    (another carrier, Beidou_B1I.h:51), three launches like bench.py's hybrid step.  Two channel-periods per signal are checked
+    against the oracle; all prompts see their signals."""
+    import torch
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    fs, n = 25_000_000, 25000
+    n_ep = 8
+    gps = [oracle.gps_l1_ca_code(prn).astype(np.float32) for prn in range(1, 17)]
+    gal = [oracle.galileo_e1_sinboc11(e1b[prn]) for prn in range(8)]
+    bds = [oracle.beidou_b1i_code(prn).astype(np.float32) for prn in range(6, 14)]
+    # L1 stream: GPS C/A at 1.023 Mcps and Galileo sinBOC samples at 2.046 M code samples per second, one noise floor
+    s_gps, t_gps = synth_stream(gps, fs, n * n_ep + 8, seed=1005, cn0_db_hz=(40.0, 48.0), noise=False)
+    s_gal, t_gal = synth_stream(gal, fs, n * n_ep + 8, seed=2005, cn0_db_hz=(40.0, 48.0), chip_rate=2 * 1.023e6)
+    l1 = (s_gps + s_gal).astype(np.complex64)
+    b1, t_bds = synth_stream(bds, fs, n * n_ep + 8, seed=3005, cn0_db_hz=(40.0, 48.0), chip_rate=2.046e6, carrier_freq=1561.098e6)
+    d_l1 = torch.from_numpy(l1.view(np.float32)).cuda()
+    d_b1 = torch.from_numpy(b1.view(np.float32)).cuda()
+    s3 = np.array([-0.5, 0.0, 0.5], np.float32)
+    s5 = np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32)
+    groups = [("gps", d_l1, l1, gps, s3, t_gps, 1023, n, n_ep, 1), ("galileo", d_l1, l1, gal, s5, t_gal, 8184, 4 * n, n_ep // 4, 2),
+        ("beidou", d_b1, b1, bds, s3, t_bds, 2046, n, n_ep, 1)]
+    rng = np.random.Generator(np.random.PCG64(7))
+    for name, d, sig, codes, shifts, truths, L, n_len, k_ep, pi in groups:
+        out = _run_group(gctx, d, sig.size, codes, shifts, truths, fs, L, n_len, k_ep)
+        for ch in range(len(codes)):
+            assert np.abs(out[ch, :, pi]).mean() > 0.6 * truths[ch]["amp"] * n_len, (name, ch)
+        for _ in range(2):
+            ch, k = int(rng.integers(len(codes))), int(rng.integers(k_ep))
+            p = open_loop_params(truths[ch], fs, L, n_len, k_ep)[k]
+            ref = oracle.multicorrelator(sig[p["sample_offset"]:], codes[ch], shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n_len)
+            assert rel_err(out[ch, k], ref, pi) <= TOL, (name, ch, k)

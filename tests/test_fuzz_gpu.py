@@ -454,7 +454,11 @@ def test_seed_4242_group_43_is_a_chip_edge_event(gctx, oracle):
     * in EVERY period the device's discriminator outputs are the reference formulas applied to the device's own accumulators
       (checked inside _compare), and each accumulator is the signed sum of the device's own correlator outputs of the
       integration (save_correlation_results, :1073-1125) -- i.e. states 3 / 4 compute the right thing on what they are given;
-    * the code error then differs by at most 2 |dE| / (|E| + |L|), which is the gate _compare uses."""
+    * the code error then differs by at most 2 |dE| / (|E| + |L|), which is the gate _compare uses.
+    Measured on MI355X (round 2, gpurun_out/seed4242_report.txt): the runs agree to rounding up to period 57 (state 2); there the L
+    tap alone differs, by 1.78375 = 2 |x[n]| (1.78317) of one of its 3 edge samples; at the recorded period 77 (3-symbol
+    integration, the loop far off its peak: pe 15.6, pl 80.7 against |P| 533) the accumulators differ by at most 6.7 = 1.89 max|x|,
+    which allows 2 sqrt(2) 6.7 / 96.2 = 0.197 in the code error; the observed gap is 0.086.  States 3 / 4 are not at fault."""
     import gnsscorr
     import torch
     from closed_loop_ref import run as ref_run

@@ -12,6 +12,9 @@
 #include "hip_multicorrelator_16sc.h"
 #include "hip_multicorrelator_real_codes.h"
 #include "pcps_acquisition_adapters.h"
+#include <array>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <thread>
@@ -492,6 +495,113 @@ static void test_wideband_acquisition()
     wideband_case<GpsL2MPcpsAcquisitionHip>("GPS L2C(M)", "Acquisition_2S", 'G', "2S", 12, fs2, 40920, 40920, 31000, -250.0f, code);
 }
 
+// The literal drop-in under load: N channel threads, one Hip_Multicorrelator_Real_Codes each, every thread calling
+// Carrier_wipeoff_multicorrelator_resampler on 25000-sample windows (one code period at 25 Msps) the way GNU Radio's
+// thread-per-block scheduler drives dll_pll_veml_tracking::do_correlation_step (dll_pll_veml_tracking.cc:886-911).
+// The calls of one context are combined by the epoch batcher: they must OVERLAP.  Two input topologies:
+//   shared   -- every thread hands in the same pointer, like the reference's own timing test (all threads read d_in,
+//               cpu_multicorrelator_real_codes_test.cc:126-146): the window goes to the GPU once per batch;
+//   distinct -- every thread reads its own offset of the stream buffer (channels at different read positions): each window
+//               crosses PCIe, which bounds the rate at ~63 GB/s / 200 KB per call.
+// Values are asserted against a float64 evaluation in both.
+static void test_level1_scales_with_channel_threads()
+{
+    const int N = 25000, n_threads = 64, calls = 40;
+    float chips[1023];
+    gc_gps_l1_ca_code_gen_float(chips, 7, 0);
+    std::vector<std::complex<float>> in(static_cast<size_t>(N) * 3 + 64);
+    unsigned lcg = 777u;
+    for (auto& v : in)
+        {
+            lcg = lcg * 1664525u + 1013904223u;
+            const float a = (lcg >> 8) * (1.0f / 16777216.0f) - 0.5f;
+            lcg = lcg * 1664525u + 1013904223u;
+            v = std::complex<float>(a, (lcg >> 8) * (1.0f / 16777216.0f) - 0.5f);
+        }
+    const float rem_carr = 0.3f, carr_step = 0.002f, code_step = 1023.0f / N, rem_code = 0.4f;
+    // float64 reference of tap sums for a window starting at `off`
+    auto want_at = [&](int off, const float* shifts, std::complex<double>* w) {
+        for (int t = 0; t < 3; t++) w[t] = 0.0;
+        for (int n = 0; n < N; n++)
+            {
+                const std::complex<double> y = std::complex<double>(in[off + n]) * std::exp(std::complex<double>(0.0, -(static_cast<double>(rem_carr) + static_cast<double>(carr_step) * n)));
+                for (int t = 0; t < 3; t++)
+                    {
+                        const float c = (code_step * static_cast<float>(n) + shifts[t]) - rem_code;  // the kernel's float32 index expression
+                        int i = static_cast<int>(std::floor(c)) % 1023;
+                        if (i < 0) i += 1023;
+                        w[t] += y * static_cast<double>(chips[i]);
+                    }
+            }
+    };
+    std::vector<std::array<float, 3>> shifts(n_threads, std::array<float, 3>{{-0.5f, 0.0f, 0.5f}});
+    std::vector<std::complex<float>> outs(3 * n_threads);
+    std::vector<Hip_Multicorrelator_Real_Codes> pool(n_threads);
+    for (int t = 0; t < n_threads; t++)
+        {
+            pool[t].set_high_dynamics_resampler(false);
+            EXPECT(pool[t].init(2 * N, 3), "init");
+            EXPECT(pool[t].set_local_code_and_taps(1023, chips, shifts[t].data()), "set_local_code_and_taps");
+        }
+    auto call = [&](int t) { return pool[t].Carrier_wipeoff_multicorrelator_resampler(rem_carr, carr_step, 0.0f, rem_code, code_step, 0.0f, N); };
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    // single-thread latency (the rate one channel thread sees alone)
+    pool[0].set_input_output_vectors(&outs[0], in.data());
+    for (int k = 0; k < 20; k++) call(0);
+    auto t0 = now();
+    for (int k = 0; k < 200; k++) call(0);
+    const double single_us = us(t0, now()) / 200.0;
+    for (int topo = 0; topo < 2; topo++)
+        {
+            const bool shared = (topo == 0);
+            std::vector<int> offs(n_threads, 0);
+            for (int t = 0; t < n_threads; t++)
+                {
+                    offs[t] = shared ? 0 : (t * 733) % (2 * N);  // distinct read positions inside one buffer
+                    pool[t].set_input_output_vectors(&outs[3 * t], in.data() + offs[t]);
+                }
+            gc_ctx* ctx = gnsscorr::shared_context();
+            uint64_t b0 = 0, r0 = 0, s0 = 0;
+            gc_correlator_batch_stats(ctx, &b0, &r0, &s0, nullptr);
+            std::atomic<int> go{0}, bad{0};
+            std::vector<std::thread> threads;
+            for (int t = 0; t < n_threads; t++)
+                threads.emplace_back([&, t]() {
+                    while (!go.load()) std::this_thread::yield();
+                    for (int k = 0; k < calls; k++)
+                        if (!call(t)) bad.fetch_add(1);
+                });
+            auto t1 = now();
+            go.store(1);
+            for (auto& th : threads) th.join();
+            const double total_us = us(t1, now());
+            uint64_t b1 = 0, r1 = 0, s1 = 0;
+            int mb = 0;
+            gc_correlator_batch_stats(ctx, &b1, &r1, &s1, &mb);
+            const double serial_us = single_us * n_threads * calls;
+            const double speedup = serial_us / total_us;
+            const double per_call = total_us / (n_threads * calls);
+            std::printf("level-1 scaling, %s input: single thread %.1f us per call; %d threads x %d calls in %.0f us = %.2f us per call (%.1fx the serial rate, "
+                        "%.0f real-time 25 Msps channels); %llu launches for %llu calls (largest batch %d), %llu calls shared an upload\n",
+                shared ? "shared" : "distinct", single_us, n_threads, calls, total_us, per_call, speedup, 1000.0 / per_call,
+                static_cast<unsigned long long>(b1 - b0), static_cast<unsigned long long>(r1 - r0), mb, static_cast<unsigned long long>(s1 - s0));
+            EXPECT(bad.load() == 0, "%d calls failed", bad.load());
+            EXPECT(r1 - r0 == static_cast<uint64_t>(n_threads) * calls, "batcher served %llu calls", static_cast<unsigned long long>(r1 - r0));
+            // the calls overlap: 64 threads finish in less than 64 x the single-thread latency / 8 when the window is shared;
+            // with distinct windows every call moves 200 KB over PCIe and the bound is the link, not the launch count
+            EXPECT(total_us < serial_us / (shared ? 8.0 : 3.0), "no overlap: %.0f us for %d x %d calls, %.1f us each alone", total_us, n_threads, calls, single_us);
+            for (int t = 0; t < n_threads; t += 7)
+                {
+                    std::complex<double> want[3];
+                    want_at(offs[t], shifts[t].data(), want);
+                    for (int k = 0; k < 3; k++)
+                        EXPECT(std::abs(std::complex<double>(outs[3 * t + k]) - want[k]) <= 2e-4 * (std::abs(want[k]) + 50.0), "thread %d tap %d: (%g,%g) vs (%g,%g)", t, k,
+                            outs[3 * t + k].real(), outs[3 * t + k].imag(), want[k].real(), want[k].imag());
+                }
+        }
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2)
@@ -507,6 +617,7 @@ int main(int argc, char** argv)
     test_multicorrelator();
     test_multicorrelator_complex();
     test_multicorrelator_16sc();
+    test_level1_scales_with_channel_threads();
     test_gps_acquisition(argv[1], false);
     test_gps_acquisition(argv[1], true);
     test_galileo_acquisition(argv[1]);

@@ -90,6 +90,7 @@ public:
                 d_status = gc_acq_set_local_code(d_acq, static_cast<int>(s), tiled.data());
             }
         d_results.resize(prns.size());
+        d_ready = (d_status == GC_OK);
     }
     ~hip_acquisition_bank()
     {
@@ -107,7 +108,7 @@ public:
     std::vector<Gnss_Synchro> search(uint64_t first_index)
     {
         std::vector<Gnss_Synchro> found;
-        if (d_status != GC_OK) return found;
+        if (d_acq == nullptr || !d_ready) return found;  // construction failed; a failed search is NOT sticky
         d_status = gc_acq_reset(d_acq);
         uint64_t stamp = first_index;
         for (uint32_t dwell = 0; dwell < d_max_dwells && d_status == GC_OK; dwell++)
@@ -143,6 +144,7 @@ public:
 private:
     gc_stream* d_ring;
     gc_acq* d_acq = nullptr;
+    bool d_ready = false;  // construction went through (every replica installed)
     char d_system;
     std::string d_signal;
     std::vector<uint32_t> d_prns;

@@ -4,7 +4,7 @@
  *
  * Same method set, argument meaning, ownership and return values as the reference class
  * (src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.h:45-69): pointers are
- * retained, every bool method returns true, the constructor leaves the high-dynamics
+ * retained, every bool method returns true when the GPU call succeeded (always, in the reference), the constructor leaves the high-dynamics
  * flag set (cpu_multicorrelator_real_codes.cc:49).  The only behavioural addition is
  * last_status(): the reference has no failure path, the GPU has (no device, HIP error);
  * a failed call leaves corr_out untouched, logs to stderr once and is visible there.
@@ -68,20 +68,19 @@ public:
 
     bool init(int max_signal_length_samples, int n_correlators)
     {
-        check(gc_correlator_init(d_corr, max_signal_length_samples, n_correlators));
-        return true;
+        d_n_corr = n_correlators;
+        return check(gc_correlator_init(d_corr, max_signal_length_samples, n_correlators));
     }
 
     bool set_local_code_and_taps(int code_length_chips, const float *local_code_in, float *shifts_chips)
     {
-        check(gc_correlator_set_local_code_and_taps(d_corr, code_length_chips, local_code_in, shifts_chips));
-        return true;
+        return check(gc_correlator_set_local_code_and_taps(d_corr, code_length_chips, local_code_in, shifts_chips));
     }
 
     bool set_input_output_vectors(std::complex<float> *corr_out, const std::complex<float> *sig_in)
     {
-        check(gc_correlator_set_input_output_vectors(d_corr, reinterpret_cast<float *>(corr_out), reinterpret_cast<const float *>(sig_in)));
-        return true;
+        d_out = corr_out;
+        return check(gc_correlator_set_input_output_vectors(d_corr, reinterpret_cast<float *>(corr_out), reinterpret_cast<const float *>(sig_in)));
     }
 
     //! The reference exposes this helper publicly; on the GPU the resampled replica is never
@@ -90,38 +89,45 @@ public:
 
     bool Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad, float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples)
     {
-        check(gc_correlator_carrier_wipeoff_multicorrelator_resampler(d_corr, rem_carrier_phase_in_rad, phase_step_rad, phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
-        return true;
+        return zero_on_failure(check(gc_correlator_carrier_wipeoff_multicorrelator_resampler(d_corr, rem_carrier_phase_in_rad, phase_step_rad, phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples)));
     }
 
     bool Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples)
     {
-        check(gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(d_corr, rem_carrier_phase_in_rad, phase_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
-        return true;
+        return zero_on_failure(check(gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(d_corr, rem_carrier_phase_in_rad, phase_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples)));
     }
 
     bool free()
     {
-        if (d_corr != nullptr) check(gc_correlator_free(d_corr));
-        return true;
+        return d_corr != nullptr ? check(gc_correlator_free(d_corr)) : false;
     }
 
     //! GC_OK, or the status of the last failed call (see gc_last_error()).
     gc_status last_status() const { return d_status; }
 
 private:
-    void check(gc_status s)
+    //! The reference's methods cannot fail and always return true; the GPU's can (no device, HIP error, bad state): the
+    //! outcome of THIS call is returned and kept in last_status() -- not sticky, a later good call reads GC_OK again.
+    bool check(gc_status s)
     {
-        if (d_corr == nullptr) return;  // construction failed: d_status keeps GC_ERR_NO_DEVICE
-        if (s != GC_OK)
-            {
-                if (d_status == GC_OK) std::fprintf(stderr, "Hip_Multicorrelator_Real_Codes: %s\n", gc_last_error());
-                d_status = s;
-            }
+        if (d_corr == nullptr) return false;  // construction failed: d_status keeps GC_ERR_NO_DEVICE
+        if (s != GC_OK && d_status == GC_OK) std::fprintf(stderr, "%s: %s\n", "Hip_Multicorrelator_Real_Codes", gc_last_error());
+        d_status = s;
+        return s == GC_OK;
+    }
+
+    //! a failed correlation must not leave the previous epoch's values for the loop to track on
+    bool zero_on_failure(bool ok)
+    {
+        if (!ok && d_out != nullptr)
+            for (int t = 0; t < d_n_corr; t++) d_out[t] = std::complex<float>(0, 0);
+        return ok;
     }
 
     gc_correlator *d_corr;
     gc_status d_status;
+    std::complex<float> *d_out = nullptr;
+    int d_n_corr = 0;
 };
 
 #endif /* GNSSCORR_HIP_MULTICORRELATOR_REAL_CODES_H_ */

@@ -61,7 +61,7 @@ public:
     gc_status start_tracking(int ch, const Gnss_Synchro& acq, uint64_t start_index)
     {
         std::lock_guard<std::mutex> l(d_mutex);
-        if (d_status != GC_OK) return d_status;
+        if (d_loop == nullptr) return d_status;  // construction failed
         if (ch < 0 || ch >= d_n) return GC_ERR_INVALID;
         if (d_active[ch]) gc_trk_loop_stop(d_loop, ch);
         gc_status st = gnsscorr::loop_start_channel(d_loop, ch, trk_parameters, d_sig, acq, start_index, d_bit_sync_min_time_s);
@@ -85,7 +85,7 @@ public:
     int run(std::vector<std::vector<Gnss_Synchro>>& out)
     {
         std::lock_guard<std::mutex> l(d_mutex);
-        if (d_status != GC_OK) return -1;
+        if (d_loop == nullptr) return -1;  // construction failed; a failed run() is NOT sticky: the next call tries again
         out.resize(d_n);
         uint64_t head = 0;
         gc_stream_info(d_ring, nullptr, &head, nullptr);
@@ -100,7 +100,12 @@ public:
         if (!any || n_periods == 0) return 0;
         d_records.resize(static_cast<size_t>(d_n) * n_periods);
         d_status = gc_trk_loop_run(d_loop, n_periods, d_records.data());
-        if (d_status != GC_OK) return -1;
+        if (d_status != GC_OK)
+            {
+                // e.g. a channel that was not serviced in time fell behind the ring (GC_ERR_STATE): the caller parks that channel
+                // (stop_tracking / a new start_tracking) and goes on; the other channels are unaffected
+                return -1;
+            }
         int produced = 0;
         for (int ch = 0; ch < d_n; ch++)
             {

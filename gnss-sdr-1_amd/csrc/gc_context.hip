@@ -27,6 +27,8 @@ void gc_ctx_release(gc_ctx* ctx)
 {
     if (ctx->refs.fetch_sub(1) != 1) return;
     gc_device_guard g(ctx->device);
+    if (void* b = ctx->l1_batcher.load())
+        if (ctx->l1_batcher_free) ctx->l1_batcher_free(b);
     if (ctx->stream)
         {
             (void)hipStreamSynchronize(ctx->stream);

@@ -40,6 +40,9 @@ struct gc_ctx
     // one reference for the creator (dropped by gc_ctx_destroy) + one per live handle created on the context:
     // the stream and the struct go away with the last of them, so handles may be destroyed in any order
     std::atomic<int> refs{1};
+    // level-1 epoch batcher (gc_tracking.hip), created on first use, released with the context
+    std::atomic<void*> l1_batcher{nullptr};
+    void (*l1_batcher_free)(void*) = nullptr;
 };
 
 void gc_ctx_retain(gc_ctx* ctx);

@@ -12,7 +12,10 @@
 #include <cmath>
 #include <complex>
 #include <cstdlib>
+#include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 // -----------------------------------------------------------------------------
@@ -560,6 +563,239 @@ static void correlator_release(gc_correlator* c)
     c->inited = false;
 }
 
+// -----------------------------------------------------------------------------
+// Level-1 epoch batcher (SURVEY.md section 7 "Latency vs batching", section 8b "one instance per channel thread").
+//
+// The reference runs one Cpu_Multicorrelator_Real_Codes per channel on that channel's scheduler thread and every thread
+// calls Carrier_wipeoff_multicorrelator_resampler once per code period (dll_pll_veml_tracking.cc:886-911,
+// gnss_flowgraph.cc:496-499).  Here those synchronous calls meet in a per-context queue: a caller that finds a free lane
+// becomes the leader of everything queued at that moment with the same kernel shape (taps, mode, sample format, slices),
+// builds ONE launch for the batch (one TrkChan + gc_epoch_params per request, results scattered to each caller's corr_out)
+// and wakes the others; requests that arrive while a batch is on the GPU form the next one, so the batch size follows the
+// load by itself (group commit: no timer, a lone caller is served at once).  Two lanes (own HIP stream and staging each)
+// keep a batch in preparation while another executes.  Callers that hand in the SAME input pointer (channels reading one
+// GNU Radio buffer position) share one DMA of the window into HBM instead of one PCIe read each.
+// -----------------------------------------------------------------------------
+struct L1Request
+{
+    TrkChan chan;
+    gc_epoch_params params;
+    int n_corr = 0, mode = 0, fmt = 0, n_slices = 1, lds_floats = 0;
+    const void* host_sig = nullptr;  // caller's sig_in (dedup key)
+    const void* pinned_sig = nullptr; // this request's page-locked copy of the window (DMA source)
+    size_t sig_bytes = 0;
+    void* out_host = nullptr;
+    size_t out_bytes = 0;
+    gc_status status = GC_OK;
+    char err[200] = "";
+    bool taken = false, done = false;
+};
+
+struct L1Lane
+{
+    hipStream_t stream = nullptr;
+    TrkChan* h_chans = nullptr;          // pinned, mapped
+    gc_epoch_params* h_params = nullptr;
+    float2* h_out = nullptr;
+    TrkChan* dv_chans = nullptr;
+    gc_epoch_params* dv_params = nullptr;
+    float2* dv_out = nullptr;
+    float2* d_partial = nullptr;
+    char* d_span = nullptr;              // windows shared by several requests of a batch, copied once
+    size_t span_cap = 0;
+    bool busy = false;
+};
+
+struct gc_l1_batcher
+{
+    static constexpr int MAXB = 256, LANES = 2, MAX_SLICES = 64;
+    int device = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<L1Request*> queue;
+    L1Lane lanes[LANES];
+    bool ok = false;
+    // statistics (gc_correlator_batch_stats)
+    unsigned long long n_batches = 0, n_requests = 0, n_shared = 0;
+    int max_batch = 0;
+};
+
+static void l1_batcher_free(void* p)
+{
+    gc_l1_batcher* b = static_cast<gc_l1_batcher*>(p);
+    for (auto& l : b->lanes)
+        {
+            if (l.stream)
+                {
+                    (void)hipStreamSynchronize(l.stream);
+                    (void)hipStreamDestroy(l.stream);
+                }
+            if (l.h_chans) (void)hipHostFree(l.h_chans);
+            if (l.h_params) (void)hipHostFree(l.h_params);
+            if (l.h_out) (void)hipHostFree(l.h_out);
+            (void)hipFree(l.d_partial);
+            (void)hipFree(l.d_span);
+        }
+    delete b;
+}
+
+// the context's batcher (created by the first caller; NULL if its buffers cannot be set up: callers then use the direct path)
+static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
+{
+    if (void* p = ctx->l1_batcher.load(std::memory_order_acquire)) return static_cast<gc_l1_batcher*>(p)->ok ? static_cast<gc_l1_batcher*>(p) : nullptr;
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (void* p = ctx->l1_batcher.load(std::memory_order_acquire)) return static_cast<gc_l1_batcher*>(p)->ok ? static_cast<gc_l1_batcher*>(p) : nullptr;
+    gc_l1_batcher* b = new gc_l1_batcher();
+    b->device = ctx->device;
+    bool ok = true;
+    for (auto& l : b->lanes)
+        {
+            void* dv = nullptr;
+            ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_chans), sizeof(TrkChan) * gc_l1_batcher::MAXB, hipHostMallocMapped) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_params), sizeof(gc_epoch_params) * gc_l1_batcher::MAXB, hipHostMallocMapped) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_out), sizeof(float2) * GC_MAX_TAPS * gc_l1_batcher::MAXB, hipHostMallocMapped) == hipSuccess;
+            ok = ok && hipHostGetDevicePointer(&dv, l.h_chans, 0) == hipSuccess;
+            l.dv_chans = static_cast<TrkChan*>(dv);
+            ok = ok && hipHostGetDevicePointer(&dv, l.h_params, 0) == hipSuccess;
+            l.dv_params = static_cast<gc_epoch_params*>(dv);
+            ok = ok && hipHostGetDevicePointer(&dv, l.h_out, 0) == hipSuccess;
+            l.dv_out = static_cast<float2*>(dv);
+            ok = ok && hipMalloc(&l.d_partial, sizeof(float2) * GC_MAX_TAPS * gc_l1_batcher::MAX_SLICES * gc_l1_batcher::MAXB) == hipSuccess;
+        }
+    if (!ok) (void)hipGetLastError();
+    b->ok = ok;
+    ctx->l1_batcher_free = &l1_batcher_free;
+    ctx->l1_batcher.store(b, std::memory_order_release);
+    return ok ? b : nullptr;
+}
+
+// runs one batch on `lane` (no lock held); fills status / err of every request
+static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>& batch, int* n_shared_out)
+{
+    gc_device_guard g(b->device);
+    const int B = (int)batch.size();
+    const L1Request& k = *batch[0];
+    int lds_floats = 0;
+    for (L1Request* r : batch) lds_floats = std::max(lds_floats, r->lds_floats);
+    hipError_t e = hipSuccess;
+    // windows handed in through the same pointer by several callers: one copy into HBM for all of them (the largest window of
+    // the group covers the others).  A caller's input is stable for the duration of its synchronous call, and all of these
+    // calls are in progress now, so the bytes are the same for every member of the group.
+    int n_shared = 0;
+    {
+        std::vector<int> order(B);
+        for (int i = 0; i < B; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int c) {
+            if (batch[a]->host_sig != batch[c]->host_sig) return batch[a]->host_sig < batch[c]->host_sig;
+            return batch[a]->sig_bytes > batch[c]->sig_bytes;
+        });
+        size_t need = 0;
+        for (int i = 0; i < B;)
+            {
+                int j = i + 1;
+                while (j < B && batch[order[j]]->host_sig == batch[order[i]]->host_sig) j++;
+                if (j - i >= 2) need += (batch[order[i]]->sig_bytes + 255) & ~(size_t)255;
+                i = j;
+            }
+        if (need > lane.span_cap)
+            {
+                (void)hipFree(lane.d_span);  // the lane is idle: nothing reads the old buffer
+                lane.d_span = nullptr;
+                lane.span_cap = 0;
+                if (hipMalloc(&lane.d_span, need) == hipSuccess) lane.span_cap = need;
+                else (void)hipGetLastError();
+            }
+        size_t off = 0;
+        for (int i = 0; i < B && e == hipSuccess;)
+            {
+                int j = i + 1;
+                while (j < B && batch[order[j]]->host_sig == batch[order[i]]->host_sig) j++;
+                const L1Request* rep = batch[order[i]];
+                const size_t bytes = (rep->sig_bytes + 255) & ~(size_t)255;
+                if (j - i >= 2 && rep->sig_bytes > 0 && off + bytes <= lane.span_cap)
+                    {
+                        e = hipMemcpyAsync(lane.d_span + off, rep->pinned_sig, rep->sig_bytes, hipMemcpyHostToDevice, lane.stream);
+                        for (int t = i; t < j; t++) batch[order[t]]->chan.iq = lane.d_span + off;
+                        n_shared += j - i;
+                        off += bytes;
+                    }
+                i = j;
+            }
+    }
+    for (int i = 0; i < B; i++)
+        {
+            lane.h_chans[i] = batch[i]->chan;
+            lane.h_params[i] = batch[i]->params;
+        }
+    if (e == hipSuccess)
+        e = trk_launch(k.n_corr, k.mode, k.fmt, lane.stream, lane.dv_chans, lane.dv_params, lane.dv_out, lane.d_partial, B, 1, k.n_slices, lds_floats);
+    if (e == hipSuccess) e = hipStreamSynchronize(lane.stream);
+    for (int i = 0; i < B; i++)
+        {
+            L1Request* r = batch[i];
+            if (e != hipSuccess)
+                {
+                    r->status = GC_ERR_HIP;
+                    std::snprintf(r->err, sizeof r->err, "tracking kernel (batch of %d) failed: %s", B, hipGetErrorString(e));
+                }
+            else
+                std::memcpy(r->out_host, reinterpret_cast<const char*>(lane.h_out) + (size_t)i * r->n_corr * (r->out_bytes / r->n_corr), r->out_bytes);
+        }
+    *n_shared_out = n_shared;
+}
+
+static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq)
+{
+    std::unique_lock<std::mutex> lk(b->m);
+    b->queue.push_back(rq);
+    while (!rq->done)
+        {
+            L1Lane* lane = nullptr;
+            if (!rq->taken)
+                for (auto& l : b->lanes)
+                    if (!l.busy)
+                        {
+                            lane = &l;
+                            break;
+                        }
+            if (!lane)
+                {
+                    b->cv.wait(lk);
+                    continue;
+                }
+            // lead: everything queued right now with the shape of the oldest request
+            std::vector<L1Request*> batch;
+            const L1Request* k = b->queue.front();
+            for (auto it = b->queue.begin(); it != b->queue.end() && (int)batch.size() < gc_l1_batcher::MAXB;)
+                {
+                    L1Request* r = *it;
+                    if (r->n_corr == k->n_corr && r->mode == k->mode && r->fmt == k->fmt && r->n_slices == k->n_slices)
+                        {
+                            r->taken = true;
+                            batch.push_back(r);
+                            it = b->queue.erase(it);
+                        }
+                    else
+                        ++it;
+                }
+            lane->busy = true;
+            lk.unlock();
+            int n_shared = 0;
+            l1_run_batch(b, *lane, batch, &n_shared);
+            lk.lock();
+            lane->busy = false;
+            for (L1Request* r : batch) r->done = true;
+            b->n_batches++;
+            b->n_requests += batch.size();
+            b->n_shared += (unsigned long long)n_shared;
+            b->max_batch = std::max(b->max_batch, (int)batch.size());
+            b->cv.notify_all();
+        }
+    if (rq->status != GC_OK) return gc_fail(rq->status, "%s", rq->err);
+    return GC_OK;
+}
+
 static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, float phase_step, float phase_rate_step,
     float rem_code, float code_step, float code_rate_step, int N)
 {
@@ -580,27 +816,40 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     GC_REQUIRE(c->code_length_chips > 0 && per_chip * (c->code_length_chips + 64) <= kMaxLdsTableFloats,
         "correlator: code_length_chips %d not supported (max %d)", c->code_length_chips, kMaxLdsTableFloats / per_chip - 64);
     gc_device_guard g(c->ctx->device);
-    std::lock_guard<std::mutex> lk(c->ctx->mtx);
+    static const bool batching = [] {
+        const char* e = std::getenv("GNSSCORR_L1_BATCH");  // 0: every call is its own launch under the context mutex (round-1 behaviour)
+        return !(e && e[0] == '0');
+    }();
+    gc_l1_batcher* bat = (c->zero_copy && batching) ? l1_batcher_get(c->ctx) : nullptr;
+    // The object's own buffers (code table, page-locked window, staging) belong to the calling thread -- one correlator per
+    // channel thread, like the reference's -- so with the batcher only the rare code upload takes the context mutex.
+    std::unique_lock<std::mutex> lk(c->ctx->mtx, std::defer_lock);
+    if (!bat) lk.lock();
     hipStream_t st = c->ctx->stream;
     const int L = c->code_length_chips;
     const int LF = per_chip * L;  // floats in the code table
     // code table: the caller's buffer is re-read on every call like the reference
     // does; it is re-uploaded only when its contents changed
-    if (LF > c->d_code_cap)
+    if (LF > c->d_code_cap || (int)c->code_shadow.size() != LF || std::memcmp(c->code_shadow.data(), c->local_code_in, sizeof(float) * LF) != 0)
         {
-            (void)hipFree(c->d_code);
-            c->d_code = nullptr;
-            c->d_code_cap = 0;
-            GC_HIP(hipMalloc(&c->d_code, sizeof(float) * LF));
-            c->d_code_cap = LF;
-            c->code_shadow.clear();
-        }
-    if ((int)c->code_shadow.size() != LF || std::memcmp(c->code_shadow.data(), c->local_code_in, sizeof(float) * LF) != 0)
-        {
+            if (bat) lk.lock();
+            if (LF > c->d_code_cap)
+                {
+                    (void)hipFree(c->d_code);
+                    c->d_code = nullptr;
+                    c->d_code_cap = 0;
+                    GC_HIP(hipMalloc(&c->d_code, sizeof(float) * LF));
+                    c->d_code_cap = LF;
+                }
             // the previous upload may still be in flight from the pageable shadow buffer
             GC_HIP(hipStreamSynchronize(st));
             c->code_shadow.assign(c->local_code_in, c->local_code_in + LF);
             GC_HIP(hipMemcpyAsync(c->d_code, c->code_shadow.data(), sizeof(float) * LF, hipMemcpyHostToDevice, st));
+            if (bat)
+                {
+                    GC_HIP(hipStreamSynchronize(st));  // batches run on the lanes' streams: the table must have landed
+                    lk.unlock();
+                }
         }
     const size_t sig_bytes = (sc16 ? sizeof(short2) : sizeof(float2)) * (size_t)N;
     const bool zc = c->zero_copy;
@@ -611,16 +860,8 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
             else
                 GC_HIP(hipMemcpyAsync(c->d_sig, c->sig_in, sig_bytes, hipMemcpyHostToDevice, st));
         }
-    gc_correlator::Staging* s = c->h_stage;
-    std::memset(&s->chan, 0, sizeof s->chan);
-    s->chan.iq = zc ? c->dv_sig : c->d_sig;
-    s->chan.n_iq = (unsigned long long)N;
-    s->chan.code = c->d_code;
-    s->chan.code_len = L;
-    for (int t = 0; t < c->n_corr; t++) s->chan.shifts[t] = c->shifts_chips[t];
-    gc_epoch_params_fill(&s->params, 0, rem_carr, phase_step, phase_rate_step, rem_code, code_step, code_rate_step, N);
-    if (!zc) GC_HIP(hipMemcpyAsync(c->d_stage, s, sizeof *s, hipMemcpyHostToDevice, st));
-    // one epoch only: cut it in slices so that the launch covers many CUs
+    // one epoch only: cut it in slices so that the launch covers many CUs.  The slice count depends on the window length alone,
+    // so a call gives the same sums whether it runs alone or inside a batch.
     int chunks = (N + 1 + 511) / 512;
     int n_slices = chunks / 2;
     static const int one_wg_max = [] {
@@ -630,11 +871,42 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     if (N <= one_wg_max) n_slices = 1;
     if (n_slices < 1) n_slices = 1;
     if (n_slices > c->partial_slices) n_slices = c->partial_slices;
+    const size_t out_bytes = (sc16 ? sizeof(short2) : sizeof(float2)) * c->n_corr;
+    if (bat)
+        {
+            L1Request rq;
+            std::memset(&rq.chan, 0, sizeof rq.chan);
+            rq.chan.iq = c->dv_sig;
+            rq.chan.n_iq = (unsigned long long)N;
+            rq.chan.code = c->d_code;
+            rq.chan.code_len = L;
+            for (int t = 0; t < c->n_corr; t++) rq.chan.shifts[t] = c->shifts_chips[t];
+            gc_epoch_params_fill(&rq.params, 0, rem_carr, phase_step, phase_rate_step, rem_code, code_step, code_rate_step, N);
+            rq.n_corr = c->n_corr;
+            rq.mode = mode;
+            rq.fmt = sc16 ? GC_IQ_I16 : GC_IQ_F32;
+            rq.n_slices = n_slices;
+            rq.lds_floats = per_chip * (L + 64);
+            rq.host_sig = c->sig_in;
+            rq.pinned_sig = c->h_sig;
+            rq.sig_bytes = sig_bytes;
+            rq.out_host = c->corr_out;
+            rq.out_bytes = out_bytes;
+            return l1_submit(bat, &rq);
+        }
+    gc_correlator::Staging* s = c->h_stage;
+    std::memset(&s->chan, 0, sizeof s->chan);
+    s->chan.iq = zc ? c->dv_sig : c->d_sig;
+    s->chan.n_iq = (unsigned long long)N;
+    s->chan.code = c->d_code;
+    s->chan.code_len = L;
+    for (int t = 0; t < c->n_corr; t++) s->chan.shifts[t] = c->shifts_chips[t];
+    gc_epoch_params_fill(&s->params, 0, rem_carr, phase_step, phase_rate_step, rem_code, code_step, code_rate_step, N);
+    if (!zc) GC_HIP(hipMemcpyAsync(c->d_stage, s, sizeof *s, hipMemcpyHostToDevice, st));
     gc_correlator::Staging* stage_dev = zc ? c->dv_stage : c->d_stage;
     hipError_t e = trk_launch(c->n_corr, mode, sc16 ? GC_IQ_I16 : GC_IQ_F32, st, &stage_dev->chan, &stage_dev->params, zc ? c->dv_out : c->d_out, c->d_partial, 1, 1,
         n_slices, per_chip * (L + 64));
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
-    const size_t out_bytes = (sc16 ? sizeof(short2) : sizeof(float2)) * c->n_corr;
     if (!zc) GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
     std::memcpy(c->corr_out, c->h_out, out_bytes);
@@ -793,6 +1065,27 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlato
     GC_REQUIRE(c, "gc_correlator_carrier_wipeoff_multicorrelator_resampler_5: NULL handle");
     return correlator_run(c, c->code_kind == gc_correlator::CODE_SC16 ? TRK_MODE_SC16 : TRK_MODE_COMPLEX_CODE, rem_carrier_phase_in_rad, phase_step_rad, 0.0f, rem_code_phase_chips,
         code_phase_step_chips, 0.0f, signal_length_samples);
+}
+
+gc_status gc_correlator_batch_stats(gc_ctx* ctx, uint64_t* n_batches, uint64_t* n_requests, uint64_t* n_shared_windows, int* max_batch)
+{
+    GC_REQUIRE(ctx, "gc_correlator_batch_stats: NULL context");
+    unsigned long long nb = 0, nr = 0, ns = 0;
+    int mb = 0;
+    if (void* p = ctx->l1_batcher.load(std::memory_order_acquire))
+        {
+            gc_l1_batcher* b = static_cast<gc_l1_batcher*>(p);
+            std::lock_guard<std::mutex> lk(b->m);
+            nb = b->n_batches;
+            nr = b->n_requests;
+            ns = b->n_shared;
+            mb = b->max_batch;
+        }
+    if (n_batches) *n_batches = nb;
+    if (n_requests) *n_requests = nr;
+    if (n_shared_windows) *n_shared_windows = ns;
+    if (max_batch) *max_batch = mb;
+    return GC_OK;
 }
 
 gc_status gc_correlator_free(gc_correlator* c)

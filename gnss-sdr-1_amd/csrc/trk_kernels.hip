@@ -40,13 +40,24 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_ke
     // (which read the same IQ window when they share an RF stream) are given the
     // same residue.
     const int b = blockIdx.x;
-    const int x = b & 7;
-    int q = b >> 3;
-    const int slice = q % n_slices;
-    q /= n_slices;
-    const int ch = q % n_channels;
-    const int epoch = (q / n_channels) * 8 + x;
-    if (epoch >= n_epochs) return;
+    int slice, ch, epoch;
+    if (n_epochs == 1)
+        {
+            // one epoch per channel (level-1 calls and their batches): no epoch dimension to spread over the XCDs
+            slice = b % n_slices;
+            ch = b / n_slices;
+            epoch = 0;
+        }
+    else
+        {
+            const int x = b & 7;
+            int q = b >> 3;
+            slice = q % n_slices;
+            q /= n_slices;
+            ch = q % n_channels;
+            epoch = (q / n_channels) * 8 + x;
+            if (epoch >= n_epochs) return;
+        }
     const int job = ch * n_epochs + epoch;
 
     const TrkChan cd = chans[ch];
@@ -154,7 +165,7 @@ hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const
     const gc_epoch_params* params, float2* out, float2* partial,
     int n_channels, int n_epochs, int n_slices, int lds_table_floats)
 {
-    const int epochs8 = (n_epochs + 7) / 8 * 8;
+    const int epochs8 = n_epochs == 1 ? 1 : (n_epochs + 7) / 8 * 8;
     dim3 grid((unsigned)((size_t)epochs8 * n_channels * n_slices));
     size_t lds_bytes = (size_t)(TRK_HDR_FLOATS + lds_table_floats) * sizeof(float);
     hipError_t e;

@@ -168,6 +168,7 @@ API = {
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler": (C.c_int, [_vp] + [C.c_float] * 6 + [C.c_int]),
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler_6": (C.c_int, [_vp] + [C.c_float] * 5 + [C.c_int]),
     "gc_correlator_free": (C.c_int, [_vp]),
+    "gc_correlator_batch_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "gc_correlator_set_local_code_and_taps_complex": (C.c_int, [_vp, C.c_int, _fp, _fp]),
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler_5": (C.c_int, [_vp] + [C.c_float] * 4 + [C.c_int]),
     "gc_correlator_set_local_code_and_taps_16sc": (C.c_int, [_vp, C.c_int, _i16p, _fp]),
@@ -445,6 +446,12 @@ class Context:
 
     def synchronize(self):
         _check(load_library().gc_ctx_synchronize(self._h))
+
+    def correlator_batch_stats(self):
+        """(launches, calls served, calls that shared their window's upload, largest batch) of the level-1 epoch batcher."""
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(load_library().gc_correlator_batch_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def close(self):
         if self._h:

@@ -109,6 +109,11 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_6(gc_correlato
     int signal_length_samples);
 /* ::free (.cc:173-186) */
 gc_status gc_correlator_free(gc_correlator* c);
+/* Engine statistics (no reference counterpart).  Concurrent calls of Carrier_wipeoff_multicorrelator_resampler from the
+ * channel threads of one context are combined into batches, one kernel launch each ("epoch batcher"): launches so far, calls
+ * served, calls whose input window was shared with another call of the same batch (same sig_in pointer: one copy to the GPU
+ * for the group), and the largest batch.  Any pointer may be NULL. */
+gc_status gc_correlator_batch_stats(gc_ctx* ctx, uint64_t* n_batches, uint64_t* n_requests, uint64_t* n_shared_windows, int* max_batch);
 
 /* The same object with COMPLEX chips is the image of Cpu_Multicorrelator
  * (cpu_multicorrelator.h:46-64; GLONASS L1/L2 and the GPS L1 C-Aid trackers):

@@ -72,7 +72,7 @@ def acq_summary():
             hbm_mb_per_search=(2.0 * f[0] + w[0]) * 1024.0 / searches_pmc / 1e6)
     dom = max(kern, key=lambda n: kern[n]["total_ms"])
     alg = 32 * 41 * 25000 * (20 + 24)
-    out = {"round": int(TAG[1:]), "workload": "bench.py acquisition: GPS L1 C/A PCPS, 25 Msps, N = 25000, 32 PRNs x 41 bins x 2 dwells",
+    out = {"round": int(TAG[1:3]), "workload": "bench.py acquisition: GPS L1 C/A PCPS, 25 Msps, N = 25000, 32 PRNs x 41 bins x 2 dwells",
         "searches_in_stats_pass": searches_stats, "searches_in_pmc_passes": searches_pmc,
         "correction": "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section), WRITE_SIZE exact; the 32 set_local_code transforms of the set-up "
                       "run the same kernels on one cell each and are included (< 1 %)",
@@ -125,7 +125,7 @@ def trk_summary():
             for r in rows:
                 w.writerow({k: (r[k][:80] if k == "Kernel_Name" else r[k]) for k in w.fieldnames})
     traffic = {
-        "round": int(TAG[1:]), "kernel": KERNEL,
+        "round": int(TAG[1:3]), "kernel": KERNEL,
         "workload": "bench.py default (32 ch x 256 epochs x 25000 samples, distinct IQ per channel)",
         "FETCH_SIZE_KB_mean": fetch, "WRITE_SIZE_KB_mean": write, "dispatches": [nf, nw],
         "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming loads, so it is doubled "

@@ -501,8 +501,10 @@ static void test_wideband_acquisition()
 // The calls of one context are combined by the epoch batcher: they must OVERLAP.  Two input topologies:
 //   shared   -- every thread hands in the same pointer, like the reference's own timing test (all threads read d_in,
 //               cpu_multicorrelator_real_codes_test.cc:126-146): the window goes to the GPU once per batch;
-//   distinct -- every thread reads its own offset of the stream buffer (channels at different read positions): each window
-//               crosses PCIe, which bounds the rate at ~63 GB/s / 200 KB per call.
+//   distinct -- every thread reads its own offset of the stream buffer (channels at different read positions): each window is
+//               staged and crosses PCIe, which bounds the rate at ~63 GB/s / 200 KB per call;
+//   registered -- the same offsets after gc_ctx_register_host_buffer on the stream buffer: no staging copies, and the windows
+//               of a batch cross PCIe once, as their union.
 // Values are asserted against a float64 evaluation in both.
 static void test_level1_scales_with_channel_threads()
 {
@@ -552,9 +554,12 @@ static void test_level1_scales_with_channel_threads()
     auto t0 = now();
     for (int k = 0; k < 200; k++) call(0);
     const double single_us = us(t0, now()) / 200.0;
-    for (int topo = 0; topo < 2; topo++)
+    const char* topo_name[3] = {"shared", "distinct", "registered"};
+    for (int topo = 0; topo < 3; topo++)
         {
             const bool shared = (topo == 0);
+            if (topo == 2)
+                EXPECT(gc_ctx_register_host_buffer(gnsscorr::shared_context(), in.data(), in.size() * sizeof(in[0])) == GC_OK, "register: %s", gc_last_error());
             std::vector<int> offs(n_threads, 0);
             for (int t = 0; t < n_threads; t++)
                 {
@@ -584,13 +589,13 @@ static void test_level1_scales_with_channel_threads()
             const double per_call = total_us / (n_threads * calls);
             std::printf("level-1 scaling, %s input: single thread %.1f us per call; %d threads x %d calls in %.0f us = %.2f us per call (%.1fx the serial rate, "
                         "%.0f real-time 25 Msps channels); %llu launches for %llu calls (largest batch %d), %llu calls shared an upload\n",
-                shared ? "shared" : "distinct", single_us, n_threads, calls, total_us, per_call, speedup, 1000.0 / per_call,
+                topo_name[topo], single_us, n_threads, calls, total_us, per_call, speedup, 1000.0 / per_call,
                 static_cast<unsigned long long>(b1 - b0), static_cast<unsigned long long>(r1 - r0), mb, static_cast<unsigned long long>(s1 - s0));
             EXPECT(bad.load() == 0, "%d calls failed", bad.load());
             EXPECT(r1 - r0 == static_cast<uint64_t>(n_threads) * calls, "batcher served %llu calls", static_cast<unsigned long long>(r1 - r0));
             // the calls overlap: 64 threads finish in less than 64 x the single-thread latency / 8 when the window is shared;
             // with distinct windows every call moves 200 KB over PCIe and the bound is the link, not the launch count
-            EXPECT(total_us < serial_us / (shared ? 8.0 : 3.0), "no overlap: %.0f us for %d x %d calls, %.1f us each alone", total_us, n_threads, calls, single_us);
+            EXPECT(total_us < serial_us / (topo == 1 ? 3.0 : 8.0), "no overlap: %.0f us for %d x %d calls, %.1f us each alone", total_us, n_threads, calls, single_us);
             for (int t = 0; t < n_threads; t += 7)
                 {
                     std::complex<double> want[3];
@@ -599,6 +604,7 @@ static void test_level1_scales_with_channel_threads()
                         EXPECT(std::abs(std::complex<double>(outs[3 * t + k]) - want[k]) <= 2e-4 * (std::abs(want[k]) + 50.0), "thread %d tap %d: (%g,%g) vs (%g,%g)", t, k,
                             outs[3 * t + k].real(), outs[3 * t + k].imag(), want[k].real(), want[k].imag());
                 }
+            if (topo == 2) EXPECT(gc_ctx_unregister_host_buffer(gnsscorr::shared_context(), in.data()) == GC_OK, "unregister: %s", gc_last_error());
         }
 }
 

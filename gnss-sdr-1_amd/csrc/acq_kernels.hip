@@ -492,6 +492,215 @@ static __device__ __forceinline__ void rows2_stage(const AcqFftPlan& plan, const
     if (!LAST) __syncthreads();  // outputs visible to the next stage
 }
 
+// ---- the same stage on PAIRS of adjacent butterflies -------------------------------------------------------------
+// One thread owns butterflies u = 2p and 2p + 1 of a row.  What that buys (N2 = 1000 = 10 x 10 x 10, the row length of every
+// 1 ms block from 2 to 25 Msps): every global access is 16 bytes per lane (first stage: A[q + M j] and A[q + 1 + M j] are
+// neighbours; last stage: outputs r + S k and r + 1 + S k are neighbours), every LDS access of the middle stages is a
+// ds_read/write_b128, and in the stages with S > 1 the two butterflies share their twiddles (same q).  Twiddles are not
+// loaded one by one any more: w^k is built from w^1 by multiplications (k = 2 .. R-1; relative error < 1e-6, against a parity
+// bar of 1e-4 of the peak), one or two loads per thread and stage instead of R - 1 (the profile of the plain version showed 116
+// vector-memory instructions per thread, most of them 8-byte twiddle loads issued right before their use, and the waves
+// waiting on them: SQ_WAIT_INST_ANY 57 % of the wave cycles at 40 % VALU utilisation).
+// Conditions (checked at compile time): R even, N2 / R even, first stage M even, other stages S even.
+template <int R, bool INV>
+static __device__ __forceinline__ void tw_powers(float2 w, float2* tw)
+{
+    tw[0] = make_float2(1.0f, 0.0f);
+    tw[1] = w;
+#pragma unroll
+    for (int k = 2; k < R; k++) tw[k] = (k % 2 == 0) ? cmul(tw[k / 2], tw[k / 2]) : cmul(tw[k - 1], w);
+}
+template <bool INV>
+static __device__ __forceinline__ float2 tmul(float2 a, float2 w) { return INV ? cmul_conj(a, w) : cmul(a, w); }
+
+typedef float acq_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int R, bool INV, int N2, int S, bool FIRST, bool LAST>
+static __device__ __forceinline__ void rows2p_stage(const AcqFftPlan& plan, const AcqRows2Args& g, float2* lds,
+    int row0, int nrow, const float2* __restrict__ twf)
+{
+    constexpr int NB = N2 / R;       // butterflies per row
+    constexpr int M = N2 / (S * R);  // sub-transform length after this stage
+    constexpr int NP = NB / 2;       // pairs per row
+    static_assert(R % 2 == 0 && NB % 2 == 0 && (FIRST ? (M % 2 == 0 && S == 1) : S % 2 == 0) && !(FIRST && LAST), "pair stage: shape not supported");
+    const int N = plan.N, N1 = plan.N1;
+    const int p = threadIdx.x;
+    const bool act = p < nrow * NP;
+    float2 a0[R], a1[R];
+    int row = 0, q = 0, r = 0, cell = 0, k1 = 0, bin = 0, sat = 0;
+    float2 w0 = make_float2(1.f, 0.f), w1 = make_float2(1.f, 0.f), wd = make_float2(1.f, 0.f);
+    if (act)
+        {
+            row = p / NP;
+            const int u = 2 * (p - row * NP);
+            q = u / S;
+            r = u - q * S;
+            if (FIRST || LAST)
+                {
+                    const float inv_n1 = 1.0f / (float)N1, inv_ns = 1.0f / (float)g.n_sats;
+                    const int rowid = row0 + row;
+                    const int cl = fdiv(rowid, inv_n1);
+                    k1 = rowid - cl * N1;
+                    bin = fdiv(cl, inv_ns);
+                    sat = cl - bin * g.n_sats;
+                    cell = sat * g.n_bins + bin;
+                }
+            // twiddle seeds first: their latency hides behind the gather below
+            if (LAST)
+                {
+                    // inter-pass twiddle w_N^(k1 * (r + S k)) = w_N^(k1 r) * (w_N^(k1 S))^k, for r and r + 1
+                    const acq_f32x4 b = *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + r);
+                    w0 = make_float2(b.x, b.y);
+                    w1 = make_float2(b.z, b.w);
+                    wd = g.wN[(size_t)k1 * N2 + S];
+                }
+            else if (FIRST)
+                {
+                    const acq_f32x4 b = *reinterpret_cast<const acq_f32x4*>(twf + q);  // w_n^q, w_n^(q+1)  (table row k = 1)
+                    w0 = make_float2(b.x, b.y);
+                    w1 = make_float2(b.z, b.w);
+                }
+            else
+                w0 = twf[q];
+            if (FIRST)
+                {
+                    const float2* ap = g.A + (size_t)bin * N + (size_t)k1 * N2 + q;
+                    if (g.B)
+                        {
+                            const float2* bp = g.B + (size_t)sat * N + (size_t)k1 * N2 + q;
+#pragma unroll
+                            for (int j = 0; j < R; j++)
+                                {
+                                    const acq_f32x4 va = *reinterpret_cast<const acq_f32x4*>(ap + M * j);
+                                    const acq_f32x4 vb = *reinterpret_cast<const acq_f32x4*>(bp + M * j);
+                                    a0[j] = cmul(make_float2(va.x, va.y), make_float2(vb.x, vb.y));
+                                    a1[j] = cmul(make_float2(va.z, va.w), make_float2(vb.z, vb.w));
+                                }
+                        }
+                    else
+                        {
+#pragma unroll
+                            for (int j = 0; j < R; j++)
+                                {
+                                    const acq_f32x4 va = *reinterpret_cast<const acq_f32x4*>(ap + M * j);
+                                    a0[j] = make_float2(va.x, va.y);
+                                    a1[j] = make_float2(va.z, va.w);
+                                }
+                        }
+                }
+            else
+                {
+                    const float2* x = lds + row * N2 + r + S * q;
+#pragma unroll
+                    for (int j = 0; j < R; j++)
+                        {
+                            const acq_f32x4 v = *reinterpret_cast<const acq_f32x4*>(x + S * M * j);
+                            a0[j] = make_float2(v.x, v.y);
+                            a1[j] = make_float2(v.z, v.w);
+                        }
+                }
+        }
+    if (!FIRST) __syncthreads();  // every input of this stage has left LDS
+    if (act)
+        {
+            dftR<R, INV>(a0);
+            dftR<R, INV>(a1);
+            float2 tw[R];
+            if (LAST)
+                {
+                    tw_powers<R, INV>(wd, tw);
+                    float2* qp = g.Q + (size_t)cell * N + (size_t)k1 * N2 + r;
+#pragma unroll
+                    for (int k = 0; k < R; k++)
+                        {
+                            const float2 o0 = tmul<INV>(a0[k], cmul(w0, tw[k]));
+                            const float2 o1 = tmul<INV>(a1[k], cmul(w1, tw[k]));
+                            *reinterpret_cast<acq_f32x4*>(qp + S * k) = acq_f32x4{o0.x, o0.y, o1.x, o1.y};
+                        }
+                }
+            else if (FIRST)
+                {
+                    // S == 1: butterfly q writes y[R q + k], k < R: 2 R contiguous elements for the pair
+                    float2* y = lds + row * N2 + R * q;
+                    tw_powers<R, INV>(w0, tw);
+#pragma unroll
+                    for (int k = 0; k < R; k += 2)
+                        {
+                            const float2 o0 = (k == 0) ? a0[0] : tmul<INV>(a0[k], tw[k]);
+                            const float2 o1 = tmul<INV>(a0[k + 1], tw[k + 1]);
+                            *reinterpret_cast<acq_f32x4*>(y + k) = acq_f32x4{o0.x, o0.y, o1.x, o1.y};
+                        }
+                    tw_powers<R, INV>(w1, tw);
+#pragma unroll
+                    for (int k = 0; k < R; k += 2)
+                        {
+                            const float2 o0 = (k == 0) ? a1[0] : tmul<INV>(a1[k], tw[k]);
+                            const float2 o1 = tmul<INV>(a1[k + 1], tw[k + 1]);
+                            *reinterpret_cast<acq_f32x4*>(y + R + k) = acq_f32x4{o0.x, o0.y, o1.x, o1.y};
+                        }
+                }
+            else
+                {
+                    // the pair shares q, hence the twiddles; outputs r + S (R q + k) and the next element
+                    tw_powers<R, INV>(w0, tw);
+                    float2* y = lds + row * N2 + r + S * R * q;
+#pragma unroll
+                    for (int k = 0; k < R; k++)
+                        {
+                            const float2 o0 = (k == 0) ? a0[0] : tmul<INV>(a0[k], tw[k]);
+                            const float2 o1 = (k == 0) ? a1[0] : tmul<INV>(a1[k], tw[k]);
+                            *reinterpret_cast<acq_f32x4*>(y + S * k) = acq_f32x4{o0.x, o0.y, o1.x, o1.y};
+                        }
+                }
+        }
+    if (!LAST) __syncthreads();  // outputs visible to the next stage
+}
+
+template <bool INV, int N2, int S, int F, int... RS>
+struct Rows2pRun;
+template <bool INV, int N2, int S, int F>
+struct Rows2pRun<INV, N2, S, F>
+{
+    static __device__ __forceinline__ void run(const AcqFftPlan&, const AcqRows2Args&, float2*, int, int) {}
+};
+template <bool INV, int N2, int S, int F, int R0, int... REST>
+struct Rows2pRun<INV, N2, S, F, R0, REST...>
+{
+    static __device__ __forceinline__ void run(const AcqFftPlan& plan, const AcqRows2Args& g, float2* lds, int row0, int nrow)
+    {
+        rows2p_stage<R0, INV, N2, S, F == 0, sizeof...(REST) == 0>(plan, g, lds, row0, nrow, g.wN2 + plan.tw_off[F]);
+        Rows2pRun<INV, N2, S * R0, F + 1, REST...>::run(plan, g, lds, row0, nrow);
+    }
+};
+template <int... RS>
+struct RowsLen;
+template <>
+struct RowsLen<>
+{
+    static constexpr int value = 1;
+};
+template <int R0, int... REST>
+struct RowsLen<R0, REST...>
+{
+    static constexpr int value = R0 * RowsLen<REST...>::value;
+};
+
+#ifndef ACQ_ROWS2P_WAVES
+#define ACQ_ROWS2P_WAVES 4
+#endif
+// radices RS...; rows per workgroup such that rows * N2 / (2 R) <= 256 threads for every stage
+template <bool INV, int... RS>
+__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS2P_WAVES) void acq_rows2p_kernel(AcqFftPlan plan, AcqRows2Args g)
+{
+    extern __shared__ float2 sm[];
+    const int per_xcd = gridDim.x >> 3;
+    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (group >= g.n_groups) return;
+    const int row0 = group * g.rpw;
+    const int nrow = min(g.rpw, g.n_rows - row0);
+    Rows2pRun<INV, RowsLen<RS...>::value, 1, 0, RS...>::run(plan, g, sm, row0, nrow);
+}
+
 // stage list: RI = R*16 + ITER per stage, run in order
 template <bool INV, int N2, int S, int F, int... RI>
 struct Rows2Run;
@@ -546,12 +755,14 @@ struct AcqRows2Entry
     int n_stages;
     int ri[4];
     AcqRows2Fn fwd, inv;
+    AcqRows2Fn pair_fwd, pair_inv;  // the same stage list on butterfly pairs (rows2p_stage), where its shape conditions hold
 };
 #define R2(r, i) ((r) * 16 + (i))
-#define ROWS2_ENTRY3(a, b, c) {3, {a, b, c, 0}, &acq_rows2_kernel<false, a, b, c>, &acq_rows2_kernel<true, a, b, c>}
-#define ROWS2_ENTRY4(a, b, c, d) {4, {a, b, c, d}, &acq_rows2_kernel<false, a, b, c, d>, &acq_rows2_kernel<true, a, b, c, d>}
+#define ROWS2_ENTRY3(a, b, c) {3, {a, b, c, 0}, &acq_rows2_kernel<false, a, b, c>, &acq_rows2_kernel<true, a, b, c>, nullptr, nullptr}
+#define ROWS2_ENTRY4(a, b, c, d) {4, {a, b, c, d}, &acq_rows2_kernel<false, a, b, c, d>, &acq_rows2_kernel<true, a, b, c, d>, nullptr, nullptr}
 static const AcqRows2Entry acq_rows2_registry[] = {
-    ROWS2_ENTRY3(R2(10, 2), R2(10, 2), R2(10, 2)),            // 1000: N = 2000 ... 25000
+    {3, {R2(10, 2), R2(10, 2), R2(10, 2), 0}, &acq_rows2_kernel<false, R2(10, 2), R2(10, 2), R2(10, 2)>, &acq_rows2_kernel<true, R2(10, 2), R2(10, 2), R2(10, 2)>,
+        &acq_rows2p_kernel<false, 10, 10, 10>, &acq_rows2p_kernel<true, 10, 10, 10>},  // 1000: N = 2000 ... 25000
     ROWS2_ENTRY3(R2(10, 1), R2(10, 1), R2(10, 1)),            // 1000, at most 2 rows per workgroup
     ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(4, 4)),             // 1024
     ROWS2_ENTRY4(R2(10, 2), R2(5, 4), R2(5, 4), R2(5, 4)),    // 1250: N = 2500, 6250, 12500
@@ -1264,7 +1475,13 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             const size_t lds2 = (size_t)g.rpw * plan.N2 * sizeof(float2);
             AcqFftPlan plan_arg = plan;
             void* args[] = {&plan_arg, &g};
-            return hipLaunchKernel(reinterpret_cast<const void*>(inverse ? entry->inv : entry->fwd), grid2, dim3(ACQ_THREADS), args, lds2, st);
+            static const bool no_pairs = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
+                return e && std::strcmp(e, "nopair") == 0;  // A/B knob: the plain packed kernel
+            }();
+            AcqRows2Fn fn = inverse ? entry->inv : entry->fwd;
+            if (!no_pairs && entry->pair_fwd) fn = inverse ? entry->pair_inv : entry->pair_fwd;
+            return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);
         }
     dim3 grid(plan.N1, n_cells);
     size_t lds = acq_rows_lds_bytes(plan);

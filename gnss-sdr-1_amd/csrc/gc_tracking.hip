@@ -12,10 +12,12 @@
 #include <cmath>
 #include <complex>
 #include <cstdlib>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <vector>
 
 // -----------------------------------------------------------------------------
@@ -576,19 +578,53 @@ static void correlator_release(gc_correlator* c)
 // keep a batch in preparation while another executes.  Callers that hand in the SAME input pointer (channels reading one
 // GNU Radio buffer position) share one DMA of the window into HBM instead of one PCIe read each.
 // -----------------------------------------------------------------------------
+// What a calling thread sleeps on.  Its own mutex, so that waking a batch's callers does not queue them up on the batcher's
+// mutex; held through shared_ptr by the request and by whoever is about to signal it (the signal is sent after the batcher's
+// mutex is released, when the request may already be gone).
+struct L1Waiter
+{
+    std::mutex m;
+    std::condition_variable cv;
+    bool signaled = false;
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return signaled; });
+        signaled = false;
+    }
+    void signal()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            signaled = true;
+        }
+        cv.notify_one();
+    }
+};
+
 struct L1Request
 {
     TrkChan chan;
     gc_epoch_params params;
     int n_corr = 0, mode = 0, fmt = 0, n_slices = 1, lds_floats = 0;
-    const void* host_sig = nullptr;  // caller's sig_in (dedup key)
-    const void* pinned_sig = nullptr; // this request's page-locked copy of the window (DMA source)
+    const char* host_sig = nullptr;    // caller's sig_in
     size_t sig_bytes = 0;
+    // where the window is read from: (a) a registered host region (region >= 0: no staging copy, device view reg_dev), or
+    // (b) this request's page-locked copy (pinned_sig / its device view in chan.iq), or (c) the copy of an EARLIER request of the
+    // queue that handed in the same pointer (rep != NULL: this request copied nothing)
+    int region = -1;
+    const char* reg_dev = nullptr;
+    const void* pinned_sig = nullptr;
+    L1Request* rep = nullptr;
+    bool copy_done = false;
     void* out_host = nullptr;
     size_t out_bytes = 0;
     gc_status status = GC_OK;
     char err[200] = "";
-    bool taken = false, done = false;
+    bool taken = false;
+    bool orphan = false;               // its representative went into a batch without it: the owner fetches the window itself
+    std::atomic<bool> done{false};     // set last by the batch's leader; the owner returns on it without taking any lock
+    std::shared_ptr<L1Waiter> waiter;  // the owner thread's
 };
 
 struct L1Lane
@@ -606,19 +642,32 @@ struct L1Lane
     bool busy = false;
 };
 
+struct L1Region
+{
+    const char* host = nullptr;
+    size_t bytes = 0;
+    const char* dev = nullptr;
+};
+
 struct gc_l1_batcher
 {
     static constexpr int MAXB = 256, LANES = 2, MAX_SLICES = 64;
     int device = 0;
     std::mutex m;
-    std::condition_variable cv;
     std::deque<L1Request*> queue;
     L1Lane lanes[LANES];
+    std::vector<L1Region> regions;   // gc_ctx_register_host_buffer
     bool ok = false;
     // statistics (gc_correlator_batch_stats)
     unsigned long long n_batches = 0, n_requests = 0, n_shared = 0;
     int max_batch = 0;
+    // $GNSSCORR_L1_TRACE=1: where a batch's time goes (microseconds, summed), printed by gc_correlator_batch_stats
+    double t_prep = 0, t_launch = 0, t_sync = 0, t_scatter = 0, t_queue = 0;
 };
+static double l1_now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static void l1_batcher_free(void* p)
 {
@@ -636,6 +685,7 @@ static void l1_batcher_free(void* p)
             (void)hipFree(l.d_partial);
             (void)hipFree(l.d_span);
         }
+    for (auto& r : b->regions) (void)hipHostUnregister(const_cast<char*>(r.host));
     delete b;
 }
 
@@ -670,67 +720,127 @@ static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
     return ok ? b : nullptr;
 }
 
+// host (mapped / registered) -> HBM copy of a shared window on the lane's stream: a kernel launch costs the calling thread
+// less than a hipMemcpyAsync, and the tracking kernel behind it needs no other ordering
+__global__ void l1_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int tail_bytes)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail_bytes)  // never reads past the end of the caller's memory
+        reinterpret_cast<char*>(dst + n16)[threadIdx.x] = reinterpret_cast<const char*>(src + n16)[threadIdx.x];
+}
+// src_dev_view and dst are 16-byte aligned
+static hipError_t l1_copy(hipStream_t st, const void* src_dev_view, void* dst, size_t bytes)
+{
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>(256, (n16 + 255) / 256);
+    hipLaunchKernelGGL(l1_copy_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, static_cast<const uint4*>(src_dev_view), static_cast<uint4*>(dst), n16,
+        (int)(bytes - n16 * 16));
+    return hipGetLastError();
+}
+
+// grows the lane's shared-window buffer (the lane is idle: nothing reads the old one)
+static bool l1_span_reserve(L1Lane& lane, size_t need)
+{
+    if (need <= lane.span_cap) return true;
+    (void)hipFree(lane.d_span);
+    lane.d_span = nullptr;
+    lane.span_cap = 0;
+    need = (need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    if (hipMalloc(&lane.d_span, need) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return false;
+        }
+    lane.span_cap = need;
+    return true;
+}
+
 // runs one batch on `lane` (no lock held); fills status / err of every request
-static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>& batch, int* n_shared_out)
+static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>& batch, const std::vector<L1Region>& regions, int* n_shared_out)
 {
     gc_device_guard g(b->device);
+    const double ta = l1_now_us();
     const int B = (int)batch.size();
     const L1Request& k = *batch[0];
     int lds_floats = 0;
     for (L1Request* r : batch) lds_floats = std::max(lds_floats, r->lds_floats);
     hipError_t e = hipSuccess;
-    // windows handed in through the same pointer by several callers: one copy into HBM for all of them (the largest window of
-    // the group covers the others).  A caller's input is stable for the duration of its synchronous call, and all of these
-    // calls are in progress now, so the bytes are the same for every member of the group.
     int n_shared = 0;
+    size_t span_off = 0;
+    // room for every shared window of this batch, reserved before any pointer into the buffer is handed out
+    bool can_share = false;
     {
-        std::vector<int> order(B);
-        for (int i = 0; i < B; i++) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](int a, int c) {
-            if (batch[a]->host_sig != batch[c]->host_sig) return batch[a]->host_sig < batch[c]->host_sig;
-            return batch[a]->sig_bytes > batch[c]->sig_bytes;
-        });
         size_t need = 0;
-        for (int i = 0; i < B;)
-            {
-                int j = i + 1;
-                while (j < B && batch[order[j]]->host_sig == batch[order[i]]->host_sig) j++;
-                if (j - i >= 2) need += (batch[order[i]]->sig_bytes + 255) & ~(size_t)255;
-                i = j;
-            }
-        if (need > lane.span_cap)
-            {
-                (void)hipFree(lane.d_span);  // the lane is idle: nothing reads the old buffer
-                lane.d_span = nullptr;
-                lane.span_cap = 0;
-                if (hipMalloc(&lane.d_span, need) == hipSuccess) lane.span_cap = need;
-                else (void)hipGetLastError();
-            }
-        size_t off = 0;
-        for (int i = 0; i < B && e == hipSuccess;)
-            {
-                int j = i + 1;
-                while (j < B && batch[order[j]]->host_sig == batch[order[i]]->host_sig) j++;
-                const L1Request* rep = batch[order[i]];
-                const size_t bytes = (rep->sig_bytes + 255) & ~(size_t)255;
-                if (j - i >= 2 && rep->sig_bytes > 0 && off + bytes <= lane.span_cap)
-                    {
-                        e = hipMemcpyAsync(lane.d_span + off, rep->pinned_sig, rep->sig_bytes, hipMemcpyHostToDevice, lane.stream);
-                        for (int t = i; t < j; t++) batch[order[t]]->chan.iq = lane.d_span + off;
-                        n_shared += j - i;
-                        off += bytes;
-                    }
-                i = j;
-            }
+        for (L1Request* r : batch)
+            if (r->sig_bytes > 0 && (r->region >= 0 || r->rep == nullptr)) need += r->sig_bytes + 512;
+        can_share = l1_span_reserve(lane, need);
     }
+    // (1) windows inside a registered host region: the callers' windows of one region overlap when the channels read
+    // neighbouring positions of one stream buffer.  When the union of the windows is clearly smaller than their sum, the union
+    // crosses PCIe ONCE (one DMA straight from the caller's page-locked memory into HBM) and every request reads its piece of
+    // it; otherwise each request reads its window from the registered memory in place.
+    for (size_t ri = 0; ri < regions.size() && e == hipSuccess && can_share; ri++)
+        {
+            const char* lo = nullptr;
+            const char* hi = nullptr;
+            size_t sum = 0;
+            int members = 0;
+            for (L1Request* r : batch)
+                if (r->region == (int)ri && r->sig_bytes > 0)
+                    {
+                        lo = (!lo || r->host_sig < lo) ? r->host_sig : lo;
+                        hi = (!hi || r->host_sig + r->sig_bytes > hi) ? r->host_sig + r->sig_bytes : hi;
+                        sum += r->sig_bytes;
+                        members++;
+                    }
+            if (members < 2) continue;
+            // the copy starts on a 16-byte boundary of the caller's memory, so every window keeps its alignment
+            const char* lo_al = lo - ((uintptr_t)lo & 15);
+            if (lo_al < regions[ri].host) continue;  // an unaligned region start: read in place
+            const size_t uni = (size_t)(hi - lo_al);
+            const size_t off = (span_off + 255) & ~(size_t)255;
+            if (uni * 3 > sum * 2 || off + uni > lane.span_cap) continue;  // nothing to gain: read in place
+            e = l1_copy(lane.stream, regions[ri].dev + (lo_al - regions[ri].host), lane.d_span + off, uni);
+            for (L1Request* r : batch)
+                if (r->region == (int)ri && r->sig_bytes > 0)
+                    {
+                        r->chan.iq = lane.d_span + off + (r->host_sig - lo_al);
+                        n_shared++;
+                    }
+            span_off = off + uni;
+        }
+    // (2) unregistered input: callers that handed in the SAME pointer share the first arrival's page-locked copy (rep);
+    // one DMA of it into HBM serves the whole group.  A caller's input is stable for the duration of its synchronous call
+    // and all of these calls are in progress now, so the bytes are the same for every member of the group.
+    for (int i = 0; i < B && e == hipSuccess; i++)
+        {
+            L1Request* rep = batch[i];
+            if (rep->region >= 0 || rep->rep != nullptr || rep->sig_bytes == 0) continue;
+            int followers = 0;
+            for (L1Request* r : batch) followers += (r->rep == rep);
+            if (!followers) continue;
+            const size_t off = (span_off + 255) & ~(size_t)255;
+            if (can_share && off + rep->sig_bytes <= lane.span_cap)
+                {
+                    e = l1_copy(lane.stream, rep->chan.iq /* device view of its page-locked copy */, lane.d_span + off, rep->sig_bytes);
+                    rep->chan.iq = lane.d_span + off;
+                    span_off = off + rep->sig_bytes;
+                }
+            for (L1Request* r : batch)
+                if (r->rep == rep) r->chan.iq = rep->chan.iq;  // the HBM copy, or the representative's page-locked buffer
+            n_shared += followers + 1;
+        }
     for (int i = 0; i < B; i++)
         {
             lane.h_chans[i] = batch[i]->chan;
             lane.h_params[i] = batch[i]->params;
         }
+    const double tb = l1_now_us();
     if (e == hipSuccess)
         e = trk_launch(k.n_corr, k.mode, k.fmt, lane.stream, lane.dv_chans, lane.dv_params, lane.dv_out, lane.d_partial, B, 1, k.n_slices, lds_floats);
+    const double tc = l1_now_us();
     if (e == hipSuccess) e = hipStreamSynchronize(lane.stream);
+    const double td = l1_now_us();
     for (int i = 0; i < B; i++)
         {
             L1Request* r = batch[i];
@@ -740,17 +850,84 @@ static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>
                     std::snprintf(r->err, sizeof r->err, "tracking kernel (batch of %d) failed: %s", B, hipGetErrorString(e));
                 }
             else
-                std::memcpy(r->out_host, reinterpret_cast<const char*>(lane.h_out) + (size_t)i * r->n_corr * (r->out_bytes / r->n_corr), r->out_bytes);
+                std::memcpy(r->out_host, reinterpret_cast<const char*>(lane.h_out) + (size_t)i * r->out_bytes, r->out_bytes);
         }
     *n_shared_out = n_shared;
+    const double te = l1_now_us();
+    std::lock_guard<std::mutex> lk(b->m);
+    b->t_prep += tb - ta;
+    b->t_launch += tc - tb;
+    b->t_sync += td - tc;
+    b->t_scatter += te - td;
 }
 
-static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq)
+static bool l1_same_shape(const L1Request* a, const L1Request* b)
 {
+    return a->n_corr == b->n_corr && a->mode == b->mode && a->fmt == b->fmt && a->n_slices == b->n_slices;
+}
+
+// a request the next leader can take: its window is in place (own copy finished, or a registered region)
+static bool l1_ready(const L1Request* r) { return !r->taken && r->copy_done && r->rep == nullptr && !r->orphan; }
+
+static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, const void* own_pinned_dev)
+{
+    const double t_in = l1_now_us();
+    struct Acc
+    {
+        gc_l1_batcher* b;
+        double t0;
+        ~Acc() { b->t_queue += l1_now_us() - t0; }  // runs with the lock released: a statistic, not a synchronised counter
+    } acc{b, t_in};
+    static thread_local std::shared_ptr<L1Waiter> my_waiter = std::make_shared<L1Waiter>();
+    rq->waiter = my_waiter;
     std::unique_lock<std::mutex> lk(b->m);
-    b->queue.push_back(rq);
-    while (!rq->done)
+    // registered region?
+    for (size_t i = 0; i < b->regions.size(); i++)
         {
+            const L1Region& g = b->regions[i];
+            if (rq->host_sig >= g.host && rq->host_sig + rq->sig_bytes <= g.host + g.bytes)
+                {
+                    rq->region = (int)i;
+                    rq->reg_dev = g.dev + (rq->host_sig - g.host);
+                    rq->chan.iq = rq->reg_dev;
+                    rq->copy_done = true;
+                    break;
+                }
+        }
+    if (rq->region < 0 && rq->sig_bytes > 0)
+        {
+            // an earlier, still queued call with the same input pointer (and kernel shape) has the window in its page-locked
+            // buffer already, or is copying it right now: follow it instead of copying the same bytes again
+            for (L1Request* r : b->queue)
+                if (!r->taken && r->rep == nullptr && r->region < 0 && r->host_sig == rq->host_sig && r->sig_bytes >= rq->sig_bytes && l1_same_shape(r, rq))
+                    {
+                        rq->rep = r;
+                        rq->copy_done = true;
+                        break;
+                    }
+        }
+    b->queue.push_back(rq);
+    bool need_copy = !rq->copy_done;
+    for (;;)
+        {
+            if (need_copy)
+                {
+                    lk.unlock();
+                    if (rq->sig_bytes > 0) std::memcpy(own_pinned, rq->host_sig, rq->sig_bytes);
+                    lk.lock();
+                    rq->pinned_sig = own_pinned;
+                    rq->chan.iq = own_pinned_dev;
+                    rq->copy_done = true;
+                    need_copy = false;
+                }
+            if (rq->done.load(std::memory_order_acquire)) break;
+            if (rq->orphan)
+                {
+                    // the call this one followed went into a batch without it (the batch was full): fetch the window itself
+                    rq->orphan = false;
+                    need_copy = true;
+                    continue;
+                }
             L1Lane* lane = nullptr;
             if (!rq->taken)
                 for (auto& l : b->lanes)
@@ -759,18 +936,33 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq)
                             lane = &l;
                             break;
                         }
-            if (!lane)
+            const L1Request* key = nullptr;
+            if (lane)
+                for (L1Request* r : b->queue)
+                    if (l1_ready(r))
+                        {
+                            key = r;
+                            break;
+                        }
+            if (!lane || !key)
                 {
-                    b->cv.wait(lk);
+                    // sleep on this thread's own waiter: whoever completes the request, frees a lane for it or detaches it
+                    // from its representative signals it
+                    lk.unlock();
+                    rq->waiter->wait();
+                    if (rq->done.load(std::memory_order_acquire)) return rq->status != GC_OK ? gc_fail(rq->status, "%s", rq->err) : GC_OK;
+                    lk.lock();
                     continue;
                 }
-            // lead: everything queued right now with the shape of the oldest request
+            // lead: everything queued right now with the shape of the oldest ready request -- the requests whose window is in
+            // place, and the followers of those (a follower sits behind its representative in the queue)
             std::vector<L1Request*> batch;
-            const L1Request* k = b->queue.front();
             for (auto it = b->queue.begin(); it != b->queue.end() && (int)batch.size() < gc_l1_batcher::MAXB;)
                 {
                     L1Request* r = *it;
-                    if (r->n_corr == k->n_corr && r->mode == k->mode && r->fmt == k->fmt && r->n_slices == k->n_slices)
+                    bool take = !r->taken && l1_same_shape(r, key) && r->copy_done;
+                    if (take && r->rep != nullptr) take = std::find(batch.begin(), batch.end(), r->rep) != batch.end();
+                    if (take)
                         {
                             r->taken = true;
                             batch.push_back(r);
@@ -779,19 +971,48 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq)
                     else
                         ++it;
                 }
+            // followers left behind by a full batch are detached now, while their representative is certainly alive
+            std::vector<std::shared_ptr<L1Waiter>> orphans;
+            for (L1Request* r : b->queue)
+                if (r->rep != nullptr && r->rep->taken)
+                    {
+                        r->rep = nullptr;
+                        r->copy_done = false;
+                        r->orphan = true;
+                        if (r != rq) orphans.push_back(r->waiter);
+                    }
+            const std::vector<L1Region> regions = b->regions;
             lane->busy = true;
             lk.unlock();
+            for (auto& w : orphans) w->signal();
             int n_shared = 0;
-            l1_run_batch(b, *lane, batch, &n_shared);
+            l1_run_batch(b, *lane, batch, regions, &n_shared);
             lk.lock();
             lane->busy = false;
-            for (L1Request* r : batch) r->done = true;
             b->n_batches++;
             b->n_requests += batch.size();
             b->n_shared += (unsigned long long)n_shared;
             b->max_batch = std::max(b->max_batch, (int)batch.size());
-            b->cv.notify_all();
+            // who to wake, collected under the lock and signalled after it is released: the batch's callers, the owner of the
+            // oldest ready request (it leads next), and followers whose representative left without them
+            std::vector<std::shared_ptr<L1Waiter>> wake;
+            bool handed = false;
+            for (L1Request* r : b->queue)
+                if (r != rq && !handed && l1_ready(r))
+                    {
+                        wake.push_back(r->waiter);
+                        handed = true;
+                    }
+            for (L1Request* r : batch)
+                {
+                    if (r != rq) wake.push_back(r->waiter);
+                    r->done.store(true, std::memory_order_release);  // r may be gone from here on (its owner returns on the flag)
+                }
+            lk.unlock();
+            for (auto& w : wake) w->signal();
+            lk.lock();
         }
+    lk.unlock();
     if (rq->status != GC_OK) return gc_fail(rq->status, "%s", rq->err);
     return GC_OK;
 }
@@ -853,7 +1074,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
         }
     const size_t sig_bytes = (sc16 ? sizeof(short2) : sizeof(float2)) * (size_t)N;
     const bool zc = c->zero_copy;
-    if (N > 0)
+    if (N > 0 && !bat)
         {
             if (zc)
                 std::memcpy(c->h_sig, c->sig_in, sig_bytes);
@@ -876,7 +1097,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
         {
             L1Request rq;
             std::memset(&rq.chan, 0, sizeof rq.chan);
-            rq.chan.iq = c->dv_sig;
+            rq.chan.iq = nullptr;  // set by the batcher: registered memory, this call's page-locked copy, or a shared HBM copy
             rq.chan.n_iq = (unsigned long long)N;
             rq.chan.code = c->d_code;
             rq.chan.code_len = L;
@@ -887,12 +1108,11 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
             rq.fmt = sc16 ? GC_IQ_I16 : GC_IQ_F32;
             rq.n_slices = n_slices;
             rq.lds_floats = per_chip * (L + 64);
-            rq.host_sig = c->sig_in;
-            rq.pinned_sig = c->h_sig;
+            rq.host_sig = reinterpret_cast<const char*>(c->sig_in);
             rq.sig_bytes = sig_bytes;
             rq.out_host = c->corr_out;
             rq.out_bytes = out_bytes;
-            return l1_submit(bat, &rq);
+            return l1_submit(bat, &rq, c->h_sig, c->dv_sig);
         }
     gc_correlator::Staging* s = c->h_stage;
     std::memset(&s->chan, 0, sizeof s->chan);
@@ -1067,6 +1287,46 @@ gc_status gc_correlator_carrier_wipeoff_multicorrelator_resampler_5(gc_correlato
         code_phase_step_chips, 0.0f, signal_length_samples);
 }
 
+gc_status gc_ctx_register_host_buffer(gc_ctx* ctx, const void* base, size_t bytes)
+{
+    GC_REQUIRE(ctx && base && bytes > 0, "gc_ctx_register_host_buffer: bad argument");
+    gc_device_guard g(ctx->device);
+    gc_l1_batcher* b = l1_batcher_get(ctx);
+    if (!b) return gc_fail(GC_ERR_HIP, "gc_ctx_register_host_buffer: the batcher's buffers could not be set up");
+    void* dv = nullptr;
+    hipError_t e = hipHostRegister(const_cast<void*>(base), bytes, hipHostRegisterMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dv, const_cast<void*>(base), 0);
+    if (e != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return gc_fail(GC_ERR_HIP, "gc_ctx_register_host_buffer: %s (the correlators keep staging their windows)", hipGetErrorString(e));
+        }
+    std::lock_guard<std::mutex> lk(b->m);
+    b->regions.push_back(L1Region{static_cast<const char*>(base), bytes, static_cast<const char*>(dv)});
+    return GC_OK;
+}
+
+gc_status gc_ctx_unregister_host_buffer(gc_ctx* ctx, const void* base)
+{
+    GC_REQUIRE(ctx && base, "gc_ctx_unregister_host_buffer: bad argument");
+    gc_device_guard g(ctx->device);
+    void* p = ctx->l1_batcher.load(std::memory_order_acquire);
+    if (!p) return gc_fail(GC_ERR_STATE, "gc_ctx_unregister_host_buffer: nothing is registered");
+    gc_l1_batcher* b = static_cast<gc_l1_batcher*>(p);
+    std::unique_lock<std::mutex> lk(b->m);
+    for (size_t i = 0; i < b->regions.size(); i++)
+        if (b->regions[i].host == base)
+            {
+                // calls in flight hold indices into the list: the slot stays, emptied
+                b->regions[i].bytes = 0;
+                lk.unlock();
+                for (auto& l : b->lanes) (void)hipStreamSynchronize(l.stream);
+                (void)hipHostUnregister(const_cast<void*>(base));
+                return GC_OK;
+            }
+    return gc_fail(GC_ERR_STATE, "gc_ctx_unregister_host_buffer: %p is not registered", base);
+}
+
 gc_status gc_correlator_batch_stats(gc_ctx* ctx, uint64_t* n_batches, uint64_t* n_requests, uint64_t* n_shared_windows, int* max_batch)
 {
     GC_REQUIRE(ctx, "gc_correlator_batch_stats: NULL context");
@@ -1080,6 +1340,10 @@ gc_status gc_correlator_batch_stats(gc_ctx* ctx, uint64_t* n_batches, uint64_t* 
             nr = b->n_requests;
             ns = b->n_shared;
             mb = b->max_batch;
+            if (const char* e = std::getenv("GNSSCORR_L1_TRACE"))
+                if (e[0] == '1' && nb)
+                    std::fprintf(stderr, "gnsscorr level-1 batcher: %llu batches, %llu calls; per batch: prepare %.1f us, launch %.1f us, wait %.1f us, scatter %.1f us; per call in the batcher %.1f us\n",
+                        nb, nr, b->t_prep / nb, b->t_launch / nb, b->t_sync / nb, b->t_scatter / nb, b->t_queue / (nr ? nr : 1));
         }
     if (n_batches) *n_batches = nb;
     if (n_requests) *n_requests = nr;

@@ -169,6 +169,8 @@ API = {
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler_6": (C.c_int, [_vp] + [C.c_float] * 5 + [C.c_int]),
     "gc_correlator_free": (C.c_int, [_vp]),
     "gc_correlator_batch_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "gc_ctx_register_host_buffer": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "gc_ctx_unregister_host_buffer": (C.c_int, [_vp, _vp]),
     "gc_correlator_set_local_code_and_taps_complex": (C.c_int, [_vp, C.c_int, _fp, _fp]),
     "gc_correlator_carrier_wipeoff_multicorrelator_resampler_5": (C.c_int, [_vp] + [C.c_float] * 4 + [C.c_int]),
     "gc_correlator_set_local_code_and_taps_16sc": (C.c_int, [_vp, C.c_int, _i16p, _fp]),

@@ -114,6 +114,14 @@ gc_status gc_correlator_free(gc_correlator* c);
  * served, calls whose input window was shared with another call of the same batch (same sig_in pointer: one copy to the GPU
  * for the group), and the largest batch.  Any pointer may be NULL. */
 gc_status gc_correlator_batch_stats(gc_ctx* ctx, uint64_t* n_batches, uint64_t* n_requests, uint64_t* n_shared_windows, int* max_batch);
+/* Optional, no reference counterpart: page-locks caller memory that the correlators of this context read their input from --
+ * typically the GNU Radio buffer behind the tracking blocks' input port (every channel's sig_in points into it,
+ * gnss_flowgraph.cc:496-499).  Windows inside a registered buffer go to the GPU without the staging copy, and the windows of one
+ * batch that overlap (channels at neighbouring read positions) cross PCIe once, as one transfer of their union.  The memory must
+ * stay valid until it is unregistered or the context is destroyed.  Fails (and changes nothing) where the runtime cannot pin the
+ * range, e.g. some doubly mapped circular buffers. */
+gc_status gc_ctx_register_host_buffer(gc_ctx* ctx, const void* base, size_t bytes);
+gc_status gc_ctx_unregister_host_buffer(gc_ctx* ctx, const void* base);
 
 /* The same object with COMPLEX chips is the image of Cpu_Multicorrelator
  * (cpu_multicorrelator.h:46-64; GLONASS L1/L2 and the GPS L1 C-Aid trackers):

@@ -100,9 +100,10 @@ int main()
         stop.store(true);
     });
 
+    HostStream streams[3];  // outlive the consumers: the final drain still queries the events recorded on them
     auto consumer = [&](int id) {
         std::mt19937_64 rng(100 + id);
-        HostStream st;
+        HostStream& st = streams[id];
         struct Job { uint64_t first, n; };
         std::mutex qm;
         std::vector<Job> q;

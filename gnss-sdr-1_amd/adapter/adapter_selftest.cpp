@@ -593,9 +593,12 @@ static void test_level1_scales_with_channel_threads()
                 static_cast<unsigned long long>(b1 - b0), static_cast<unsigned long long>(r1 - r0), mb, static_cast<unsigned long long>(s1 - s0));
             EXPECT(bad.load() == 0, "%d calls failed", bad.load());
             EXPECT(r1 - r0 == static_cast<uint64_t>(n_threads) * calls, "batcher served %llu calls", static_cast<unsigned long long>(r1 - r0));
-            // the calls overlap: 64 threads finish in less than 64 x the single-thread latency / 8 when the window is shared;
-            // with distinct windows every call moves 200 KB over PCIe and the bound is the link, not the launch count
-            EXPECT(total_us < serial_us / (topo == 1 ? 3.0 : 8.0), "no overlap: %.0f us for %d x %d calls, %.1f us each alone", total_us, n_threads, calls, single_us);
+            // The calls overlap.  With the stream buffer registered, 64 threads finish in less than 64 x the single-thread latency / 8
+            // (measured 9.5-10x).  Unregistered input is staged by the calling threads (200 KB each, 64 threads on the box's 16
+            // cores) and every thread sleeps and is woken once per call: measured 5.9-7.6x with a shared window, 4.0-4.5x with
+            // distinct ones; the gates leave room for the scheduler's mood.
+            const bool timing_gates = std::getenv("GNSSCORR_SELFTEST_NO_TIMING") == nullptr;  // sanitizer builds check values only
+            EXPECT(!timing_gates || total_us < serial_us / (topo == 2 ? 8.0 : topo == 0 ? 4.5 : 3.0), "no overlap: %.0f us for %d x %d calls, %.1f us each alone", total_us, n_threads, calls, single_us);
             for (int t = 0; t < n_threads; t += 7)
                 {
                     std::complex<double> want[3];

@@ -82,6 +82,8 @@ struct AcqFinalArgs
     const unsigned* blk_max_idx;
     const float* input_power;
     gc_acq_result* results;
+    float* part_val;     // [sat][ACQ_FINAL_PIECES][2]: second-peak candidates of the row pieces
+    unsigned* part_cnt;  // [sat]: ticket counters, zero between launches
     int n_bins, n_blocks, fft_size;
     int doppler_max, doppler_step;
     int use_cfar;
@@ -91,6 +93,7 @@ struct AcqFinalArgs
     float center_step_two, doppler_step2;
     int n_bins_step2;
 };
+#define ACQ_FINAL_PIECES 8  // = ACQ_FINAL_SPLIT of acq_kernels.hip
 hipError_t acq_launch_final(hipStream_t st, const AcqFinalArgs& a, int n_sats);
 
 #endif

@@ -373,6 +373,7 @@ struct AcqRows2Args
     int n_bins;  // cells per satellite (= mapA.mod)
     int n_sats;  // satellites in this launch; cell = sat * n_bins + bin
     int n_groups;  // workgroups that have rows
+    int sat_fastest;  // pair kernel: row order (bin, k1, sat) instead of (bin, sat, k1)
 };
 
 // floor(a / b) for 0 <= a < 2^22 given inv_b = 1.0f / b
@@ -539,10 +540,22 @@ static __device__ __forceinline__ void rows2p_stage(const AcqFftPlan& plan, cons
                 {
                     const float inv_n1 = 1.0f / (float)N1, inv_ns = 1.0f / (float)g.n_sats;
                     const int rowid = row0 + row;
-                    const int cl = fdiv(rowid, inv_n1);
-                    k1 = rowid - cl * N1;
-                    bin = fdiv(cl, inv_ns);
-                    sat = cl - bin * g.n_sats;
+                    if (g.sat_fastest)
+                        {
+                            // (bin, k1, sat): the rows of a workgroup are the SAME row of the signal spectrum for neighbouring
+                            // satellites, so its A loads hit the CU's L1 after the first row's
+                            const int bk = fdiv(rowid, inv_ns);
+                            sat = rowid - bk * g.n_sats;
+                            bin = fdiv(bk, inv_n1);
+                            k1 = bk - bin * N1;
+                        }
+                    else
+                        {
+                            const int cl = fdiv(rowid, inv_n1);
+                            k1 = rowid - cl * N1;
+                            bin = fdiv(cl, inv_ns);
+                            sat = cl - bin * g.n_sats;
+                        }
                     cell = sat * g.n_bins + bin;
                 }
             // twiddle seeds first: their latency hides behind the gather below
@@ -1128,8 +1141,15 @@ __global__ __launch_bounds__(1024) void acq_input_power_kernel(const float2* __r
         }
 }
 
-// ---- final statistics, one workgroup per satellite ----
-#define ACQ_FINAL_THREADS 1024
+// ---- final statistics ----
+// The peak search over the per-block row maxima is cheap (n_bins * n_blocks entries) and done by every workgroup; the second-peak
+// scan of the peak's row (N elements, ~35 instructions each) is cut into ACQ_FINAL_SPLIT pieces, one workgroup each, so that a
+// satellite's statistic is not the work of a single CU (one 1024-thread workgroup per satellite took 18-20 us for N = 25000, on 32
+// of the chip's 256 CUs).  The last workgroup of a satellite to finish combines the pieces (ticket counter in global memory, reset
+// for the next launch; release / acquire fences at agent scope around it).
+#define ACQ_FINAL_SPLIT 8
+static_assert(ACQ_FINAL_SPLIT == ACQ_FINAL_PIECES, "acq_kernels.h sizes the hand-over buffer");
+#define ACQ_FINAL_THREADS 256
 struct MaxKey
 {
     float v;
@@ -1143,13 +1163,15 @@ static __device__ __forceinline__ MaxKey max_key(MaxKey a, MaxKey b)
 __global__ __launch_bounds__(ACQ_FINAL_THREADS) void acq_final_kernel(AcqFinalArgs a)
 {
     const int sat = blockIdx.x;
+    const int piece = blockIdx.y;
     const int N = a.fft_size;
     const int tid = threadIdx.x;
+    constexpr int NW = ACQ_FINAL_THREADS / 64;
     __shared__ float s_peak;
     __shared__ unsigned s_row, s_time;
-    __shared__ float sv[ACQ_FINAL_THREADS / 64];
-    __shared__ unsigned long long sk[ACQ_FINAL_THREADS / 64];
-    __shared__ unsigned si[ACQ_FINAL_THREADS / 64];
+    __shared__ float sv[NW];
+    __shared__ unsigned long long sk[NW];
+    __shared__ unsigned si[NW];
     {
         // Global maximum over the per-block row maxima.  The reference scans rows in increasing Doppler
         // with a strict '>' on the row maxima (pcps_acquisition.cc:575-585 / :611-621), each row maximum
@@ -1162,8 +1184,9 @@ __global__ __launch_bounds__(ACQ_FINAL_THREADS) void acq_final_kernel(AcqFinalAr
                 const int d = i / a.n_blocks;
                 const size_t e = ((size_t)sat * a.n_bins + d) * a.n_blocks + (i % a.n_blocks);
                 const unsigned idx = a.blk_max_idx[e];
+                const float val = a.blk_max_val[e];
                 if (idx == 0xffffffffu) continue;  // block without kept samples
-                MaxKey c = {a.blk_max_val[e], (unsigned long long)d * (unsigned long long)N + idx};
+                MaxKey c = {val, (unsigned long long)d * (unsigned long long)N + idx};
                 b = max_key(b, c);
             }
 #pragma unroll
@@ -1182,7 +1205,7 @@ __global__ __launch_bounds__(ACQ_FINAL_THREADS) void acq_final_kernel(AcqFinalAr
         __syncthreads();
         if (tid == 0)
             {
-                for (int w = 1; w < ACQ_FINAL_THREADS / 64; w++)
+                for (int w = 1; w < NW; w++)
                     {
                         MaxKey c = {sv[w], sk[w]};
                         b = max_key(b, c);
@@ -1213,98 +1236,122 @@ __global__ __launch_bounds__(ACQ_FINAL_THREADS) void acq_final_kernel(AcqFinalAr
     r.second_peak = 0.0f;
     r.second_peak_full_row = 0.0f;
     r.test_statistics = 0.0f;
+    // :764-768
+    r.acq_delay_samples = (double)fmodf((float)tim, a.samples_per_code);
+    r.acq_doppler_hz = (double)r.doppler_hz;
     if (a.use_cfar)
         {
             // max_to_input_power_statistic (:571,594-595)
             float nf = (float)N * (float)N;
             float magt = peak / (nf * nf);
             r.test_statistics = magt / r.input_power;
+            if (tid == 0 && piece == 0) a.results[sat] = r;
+            return;
         }
-    else
+    // first_vs_second_peak_statistic (:627-664)
+    int e1 = (int)tim - a.samples_per_chip;
+    int e2 = (int)tim + a.samples_per_chip;
+    if (e1 < 0)
+        e1 = N + e1;
+    else if (e2 >= N)
+        e2 = e2 - N;
+    int len = e2 - e1;  // the do-while clears e1, e1+1, ... (circular) up to but excluding e2
+    if (len <= 0) len += N;
+    const float* grow = a.grid + ((size_t)sat * a.n_bins + row) * N;
+    float* tmp = a.tmp + (size_t)sat * N;
+    // memcpy(d_tmp_buffer, row, d_fft_size) copies d_fft_size BYTES = N/4 floats (:647)
+    const int n_copied = N / 4;
+    MaxPair best_bug = {-1.0f, 0xffffffffu}, best_full = {-1.0f, 0xffffffffu};
+    // this workgroup's piece of the row; U elements per thread and step, the 2 U loads issued before the first one is used
+    const int per_piece = (N + ACQ_FINAL_SPLIT - 1) / ACQ_FINAL_SPLIT;
+    const int p0 = piece * per_piece, p1 = min(N, p0 + per_piece);
+    constexpr int U = 16;  // N = 25000: 3125 elements per piece, one step (a step is one memory round trip)
+    for (int i0 = p0 + tid; i0 < p1; i0 += U * ACQ_FINAL_THREADS)
         {
-            // first_vs_second_peak_statistic (:627-664)
-            int e1 = (int)tim - a.samples_per_chip;
-            int e2 = (int)tim + a.samples_per_chip;
-            if (e1 < 0)
-                e1 = N + e1;
-            else if (e2 >= N)
-                e2 = e2 - N;
-            int len = e2 - e1;  // the do-while clears e1, e1+1, ... (circular) up to but excluding e2
-            if (len <= 0) len += N;
-            const float* grow = a.grid + ((size_t)sat * a.n_bins + row) * N;
-            float* tmp = a.tmp + (size_t)sat * N;
-            // memcpy(d_tmp_buffer, row, d_fft_size) copies d_fft_size BYTES = N/4 floats (:647)
-            const int n_copied = N / 4;
-            MaxPair best_bug = {-1.0f, 0xffffffffu}, best_full = {-1.0f, 0xffffffffu};
-            // four elements per thread and step: the eight loads are issued before the first one is used (one dependent
-            // load per element made this loop the whole 24 us of the kernel)
-            constexpr int U = 4;
-            for (int i0 = tid; i0 < N; i0 += U * ACQ_FINAL_THREADS)
+            float g[U], t[U];
+#pragma unroll
+            for (int u = 0; u < U; u++)
                 {
-                    float g[U], t[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++)
-                        {
-                            const int i = i0 + u * ACQ_FINAL_THREADS;
-                            g[u] = i < N ? grow[i] : 0.0f;
-                            t[u] = (i < N && i >= n_copied) ? tmp[i] : 0.0f;
-                        }
-#pragma unroll
-                    for (int u = 0; u < U; u++)
-                        {
-                            const int i = i0 + u * ACQ_FINAL_THREADS;
-                            if (i >= N) continue;
-                            int d = i - e1;
-                            if (d < 0) d += N;
-                            const bool excluded = d < len;
-                            float vb = (i < n_copied) ? g[u] : t[u];
-                            float vf = g[u];
-                            if (excluded)
-                                {
-                                    vb = 0.0f;
-                                    vf = 0.0f;
-                                }
-                            tmp[i] = vb;  // the scratch keeps these contents for the next call, like d_tmp_buffer
-                            MaxPair cb = {vb, (unsigned)i}, cf = {vf, (unsigned)i};
-                            best_bug = max_pair(best_bug, cb);
-                            best_full = max_pair(best_full, cf);
-                        }
+                    const int i = i0 + u * ACQ_FINAL_THREADS;
+                    g[u] = i < p1 ? grow[i] : 0.0f;
+                    t[u] = (i < p1 && i >= n_copied) ? tmp[i] : 0.0f;
                 }
-            for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+            for (int u = 0; u < U; u++)
                 {
-                    MaxPair b = pass ? best_full : best_bug;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1)
+                    const int i = i0 + u * ACQ_FINAL_THREADS;
+                    if (i >= p1) continue;
+                    int d = i - e1;
+                    if (d < 0) d += N;
+                    const bool excluded = d < len;
+                    float vb = (i < n_copied) ? g[u] : t[u];
+                    float vf = g[u];
+                    if (excluded)
                         {
-                            MaxPair o;
-                            o.v = __shfl_down(b.v, off, 64);
-                            o.i = __shfl_down(b.i, off, 64);
-                            b = max_pair(b, o);
+                            vb = 0.0f;
+                            vf = 0.0f;
                         }
-                    __syncthreads();
-                    if ((tid & 63) == 0)
-                        {
-                            sv[tid >> 6] = b.v;
-                            si[tid >> 6] = b.i;
-                        }
-                    __syncthreads();
-                    MaxPair t = {sv[0], si[0]};
-                    for (int w = 1; w < ACQ_FINAL_THREADS / 64; w++)
-                        {
-                            MaxPair c = {sv[w], si[w]};
-                            t = max_pair(t, c);
-                        }
-                    if (pass)
-                        r.second_peak_full_row = t.v;
-                    else
-                        r.second_peak = t.v;
+                    tmp[i] = vb;  // the scratch keeps these contents for the next call, like d_tmp_buffer
+                    MaxPair cb = {vb, (unsigned)i}, cf = {vf, (unsigned)i};
+                    best_bug = max_pair(best_bug, cb);
+                    best_full = max_pair(best_full, cf);
                 }
-            r.test_statistics = peak / r.second_peak;
         }
-    // :764-768
-    r.acq_delay_samples = (double)fmodf((float)tim, a.samples_per_code);
-    r.acq_doppler_hz = (double)r.doppler_hz;
-    if (tid == 0) a.results[sat] = r;
+    float piece_val[2];
+    for (int pass = 0; pass < 2; pass++)
+        {
+            MaxPair b = pass ? best_full : best_bug;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                {
+                    MaxPair o;
+                    o.v = __shfl_down(b.v, off, 64);
+                    o.i = __shfl_down(b.i, off, 64);
+                    b = max_pair(b, o);
+                }
+            __syncthreads();
+            if ((tid & 63) == 0)
+                {
+                    sv[tid >> 6] = b.v;
+                    si[tid >> 6] = b.i;
+                }
+            __syncthreads();
+            MaxPair t = {sv[0], si[0]};
+            for (int w = 1; w < NW; w++)
+                {
+                    MaxPair c = {sv[w], si[w]};
+                    t = max_pair(t, c);
+                }
+            piece_val[pass] = t.v;  // only the VALUE of the second peak is used (first / second), not its position
+        }
+    if (tid == 0)
+        {
+            // hand the piece over; the workgroup that draws the last ticket combines (all in one lane: store -> release fence ->
+            // ticket, ticket -> acquire fence -> loads)
+            float* pv = a.part_val + ((size_t)sat * ACQ_FINAL_SPLIT + piece) * 2;
+            __hip_atomic_store(pv + 0, piece_val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pv + 1, piece_val[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(a.part_cnt + sat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == ACQ_FINAL_SPLIT - 1)
+                {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    float sb = -1.0f, sf = -1.0f;
+                    for (int q = 0; q < ACQ_FINAL_SPLIT; q++)
+                        {
+                            const float* qv = a.part_val + ((size_t)sat * ACQ_FINAL_SPLIT + q) * 2;
+                            sb = fmaxf(sb, __hip_atomic_load(qv + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            sf = fmaxf(sf, __hip_atomic_load(qv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                    r.second_peak = sb;
+                    r.second_peak_full_row = sf;
+                    r.test_statistics = peak / r.second_peak;
+                    a.results[sat] = r;
+                    __hip_atomic_store(a.part_cnt + sat, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                }
+        }
 }
 
 // -----------------------------------------------------------------------------
@@ -1481,6 +1528,11 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             }();
             AcqRows2Fn fn = inverse ? entry->inv : entry->fwd;
             if (!no_pairs && entry->pair_fwd) fn = inverse ? entry->pair_inv : entry->pair_fwd;
+            static const int row_order = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");  // A/B knob: 0 = (bin, sat, k1), 1 = (bin, k1, sat)
+                return e ? std::atoi(e) : 1;
+            }();
+            g.sat_fastest = (B != nullptr && g.n_sats > 1) ? row_order : 0;
             return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);
         }
     dim3 grid(plan.N1, n_cells);
@@ -1595,6 +1647,6 @@ hipError_t acq_launch_input_power(hipStream_t st, const float2* x, int n_valid, 
 
 hipError_t acq_launch_final(hipStream_t st, const AcqFinalArgs& a, int n_sats)
 {
-    hipLaunchKernelGGL(acq_final_kernel, dim3(n_sats), dim3(ACQ_FINAL_THREADS), 0, st, a);
+    hipLaunchKernelGGL(acq_final_kernel, dim3(n_sats, a.use_cfar ? 1 : ACQ_FINAL_SPLIT), dim3(ACQ_FINAL_THREADS), 0, st, a);
     return hipGetLastError();
 }

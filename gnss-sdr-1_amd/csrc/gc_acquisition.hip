@@ -47,6 +47,8 @@ struct gc_acq
     int iq_format = GC_IQ_F32;
     gc_acq_result* d_results = nullptr;
     gc_acq_result* h_results = nullptr;  // pinned
+    float* d_part_val = nullptr;      // acq_final_kernel: second-peak candidates per row piece
+    unsigned* d_part_cnt = nullptr;   // and its ticket counters
     std::vector<char> code_set;
     int64_t freq_offset_hz = 0;  // d_old_freq: intermediate frequency / GLONASS FDMA channel offset
     bool grid_logically_zero = true;  // gc_acq_reset() since the last dwell: the grid reads as zeros
@@ -70,6 +72,8 @@ static void acq_release(gc_acq* a)
     (void)hipFree(a->d_in);
     (void)hipFree(a->d_cvt);
     (void)hipFree(a->d_results);
+    (void)hipFree(a->d_part_val);
+    (void)hipFree(a->d_part_cnt);
     if (a->h_results) (void)hipHostFree(a->h_results);
 }
 
@@ -189,6 +193,9 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     ACQ_TRY(hipMalloc(&a->d_in, N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_cvt, N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_results, (size_t)n_sats * sizeof(gc_acq_result)));
+    ACQ_TRY(hipMalloc(&a->d_part_val, (size_t)n_sats * ACQ_FINAL_PIECES * 2 * sizeof(float)));
+    ACQ_TRY(hipMalloc(&a->d_part_cnt, (size_t)n_sats * sizeof(unsigned)));
+    ACQ_TRY(hipMemset(a->d_part_cnt, 0, (size_t)n_sats * sizeof(unsigned)));
     ACQ_TRY(hipHostMalloc(reinterpret_cast<void**>(&a->h_results), (size_t)n_sats * sizeof(gc_acq_result), hipHostMallocDefault));
     a->code_set.assign(n_sats, 0);
 
@@ -394,6 +401,8 @@ static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hi
             f.blk_max_idx = a->d_blki;
             f.input_power = (a->use_cfar || bt) ? a->d_power : nullptr;
             f.results = a->d_results;
+            f.part_val = a->d_part_val;
+            f.part_cnt = a->d_part_cnt;
             f.n_bins = n_bins;
             f.n_blocks = a->n_blocks;
             f.fft_size = (int)N;

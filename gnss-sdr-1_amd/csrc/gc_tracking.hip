@@ -658,6 +658,7 @@ struct gc_l1_batcher
     L1Lane lanes[LANES];
     std::vector<L1Region> regions;   // gc_ctx_register_host_buffer
     bool ok = false;
+    int min_second_lane = 16;  // $GNSSCORR_L1_SECOND_LANE: ready calls needed to start a batch while another one is running
     // statistics (gc_correlator_batch_stats)
     unsigned long long n_batches = 0, n_requests = 0, n_shared = 0;
     int max_batch = 0;
@@ -697,6 +698,7 @@ static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
     if (void* p = ctx->l1_batcher.load(std::memory_order_acquire)) return static_cast<gc_l1_batcher*>(p)->ok ? static_cast<gc_l1_batcher*>(p) : nullptr;
     gc_l1_batcher* b = new gc_l1_batcher();
     b->device = ctx->device;
+    if (const char* e = std::getenv("GNSSCORR_L1_SECOND_LANE")) b->min_second_lane = std::max(1, std::atoi(e));
     bool ok = true;
     for (auto& l : b->lanes)
         {
@@ -938,12 +940,21 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, co
                         }
             const L1Request* key = nullptr;
             if (lane)
-                for (L1Request* r : b->queue)
-                    if (l1_ready(r))
-                        {
-                            key = r;
-                            break;
-                        }
+                {
+                    int n_ready = 0;
+                    bool other_busy = false;
+                    for (auto& l : b->lanes) other_busy |= l.busy;
+                    for (L1Request* r : b->queue)
+                        if (l1_ready(r))
+                            {
+                                if (!key) key = r;
+                                n_ready++;
+                            }
+                    // A batch costs about the same whether it carries one call or fifty (launch + completion latency), so a
+                    // second lane is opened only for a batch worth it; a handful of calls wait for the running batch to finish
+                    // and are joined by everything that arrives meanwhile.
+                    if (other_busy && n_ready < b->min_second_lane) key = nullptr;
+                }
             if (!lane || !key)
                 {
                     // sleep on this thread's own waiter: whoever completes the request, frees a lane for it or detaches it

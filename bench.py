@@ -170,7 +170,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (rehearsal, tests/test_bench_dist_gpu.py): initialise the process group for ONE rank too, so that the
+    # RCCL branch -- init with device_id, barrier, MAX all-reduce of the elapsed time -- runs on a single-GPU box
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

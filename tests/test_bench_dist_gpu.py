@@ -1,0 +1,30 @@
+"""The driver's multi-GPU launch shape on the one GPU a test box has: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 1
+--master-addr 127.0.0.1 ... bench.py --gpus 1` with the process group forced on (BENCH_FORCE_DIST=1), so that bench.py's RCCL branch
+(`init_process_group("nccl", device_id=...)`, the barriers, the MAX all-reduce of the elapsed time on the device) executes for real.
+The N > 1 sharding logic itself is covered by the 2-rank gloo test (tests/test_sharding.py); 8 GPUs are the driver's to launch."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_under_torchrun_with_rccl_process_group():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--epochs", "16", "--no-cpu", "--no-acq", "--no-shared"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["roofline"]["traffic"] is None  # another workload than the profiled one: no borrowed counter figure

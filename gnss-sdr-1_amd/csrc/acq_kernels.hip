@@ -714,6 +714,217 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS2P_WAVES) void acq_rows2p_kern
     Rows2pRun<INV, RowsLen<RS...>::value, 1, 0, RS...>::run(plan, g, sm, row0, nrow);
 }
 
+// ---- N2 = 1000 = 10 x 10 x 10 on butterfly pairs, PLANAR and packed across the pair ----------------------------------------
+// Same decomposition as rows2p_stage (a thread owns butterflies u = 2p, 2p + 1 of a row; 16-byte global accesses; twiddles from
+// seeds), but the registers hold (butterfly 0, butterfly 1) pairs of REAL parts and of IMAGINARY parts: every operation of the
+// radix-10 butterfly is then one packed-FP32 instruction that serves both butterflies with no component shuffles.  The
+// interleaved form above packs (re, im) of one value, which the +-j rotations and the constant twiddles of the DFT keep taking
+// apart: its disassembly has 250 register moves among 1148 VALU instructions per wave.  LDS holds the rows as two planes (re,
+// im) so that a pair's inputs and outputs of the LDS stages are 8-byte accesses of one plane each.
+typedef float acq_pk2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ acq_pk2 pfma(acq_pk2 a, acq_pk2 b, acq_pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+static __device__ __forceinline__ acq_pk2 psplat(float c) { return acq_pk2{c, c}; }
+struct PkC  // a complex value per butterfly of the pair
+{
+    acq_pk2 r, i;
+};
+static __device__ __forceinline__ PkC pk_mul(PkC a, PkC b) { return PkC{pfma(a.r, b.r, -(a.i * b.i)), pfma(a.r, b.i, a.i * b.r)}; }
+static __device__ __forceinline__ PkC pk_mul_conj(PkC a, PkC b) { return PkC{pfma(a.r, b.r, a.i * b.i), pfma(a.i, b.r, -(a.r * b.i))}; }
+template <bool INV>
+static __device__ __forceinline__ PkC pk_tmul(PkC a, PkC w) { return INV ? pk_mul_conj(a, w) : pk_mul(a, w); }
+static __device__ __forceinline__ PkC pk_add(PkC a, PkC b) { return PkC{a.r + b.r, a.i + b.i}; }
+static __device__ __forceinline__ PkC pk_sub(PkC a, PkC b) { return PkC{a.r - b.r, a.i - b.i}; }
+// a + (-j) b (forward) / a + j b (inverse), and the same with the opposite sign of b
+template <bool INV>
+static __device__ __forceinline__ PkC pk_add_mj(PkC a, PkC b) { return INV ? PkC{a.r - b.i, a.i + b.r} : PkC{a.r + b.i, a.i - b.r}; }
+template <bool INV>
+static __device__ __forceinline__ PkC pk_sub_mj(PkC a, PkC b) { return INV ? PkC{a.r + b.i, a.i - b.r} : PkC{a.r - b.i, a.i + b.r}; }
+// a * exp(-+j phi) for a constant phi
+template <bool INV>
+static __device__ __forceinline__ PkC pk_mul_const(PkC a, float c, float sn)
+{
+    const acq_pk2 cc = psplat(c), ss = psplat(sn);
+    return INV ? PkC{pfma(a.r, cc, -(a.i * ss)), pfma(a.i, cc, a.r * ss)} : PkC{pfma(a.r, cc, a.i * ss), pfma(a.i, cc, -(a.r * ss))};
+}
+template <bool INV>
+static __device__ __forceinline__ void pk_dft5(PkC* a)
+{
+    const acq_pk2 c1 = psplat(0.30901699437494742410f), c2 = psplat(-0.80901699437494742410f);
+    const acq_pk2 s1 = psplat(0.95105651629515357212f), s2 = psplat(0.58778525229247312917f);
+    const PkC t1 = pk_add(a[1], a[4]), t2 = pk_add(a[2], a[3]), t3 = pk_sub(a[1], a[4]), t4 = pk_sub(a[2], a[3]);
+    const PkC m1 = {pfma(c2, t2.r, pfma(c1, t1.r, a[0].r)), pfma(c2, t2.i, pfma(c1, t1.i, a[0].i))};
+    const PkC m2 = {pfma(c1, t2.r, pfma(c2, t1.r, a[0].r)), pfma(c1, t2.i, pfma(c2, t1.i, a[0].i))};
+    const PkC v1 = {pfma(s2, t4.r, s1 * t3.r), pfma(s2, t4.i, s1 * t3.i)};
+    const PkC v2 = {pfma(s2, t3.r, -(s1 * t4.r)), pfma(s2, t3.i, -(s1 * t4.i))};
+    a[0] = pk_add(a[0], pk_add(t1, t2));
+    a[1] = pk_add_mj<INV>(m1, v1);
+    a[4] = pk_sub_mj<INV>(m1, v1);
+    a[2] = pk_add_mj<INV>(m2, v2);
+    a[3] = pk_sub_mj<INV>(m2, v2);
+}
+template <bool INV>
+static __device__ __forceinline__ void pk_dft10(PkC* a)
+{
+    PkC e[5] = {a[0], a[2], a[4], a[6], a[8]};
+    PkC o[5] = {a[1], a[3], a[5], a[7], a[9]};
+    pk_dft5<INV>(e);
+    pk_dft5<INV>(o);
+    o[1] = pk_mul_const<INV>(o[1], 0.80901699437494742410f, 0.58778525229247312917f);
+    o[2] = pk_mul_const<INV>(o[2], 0.30901699437494742410f, 0.95105651629515357212f);
+    o[3] = pk_mul_const<INV>(o[3], -0.30901699437494742410f, 0.95105651629515357212f);
+    o[4] = pk_mul_const<INV>(o[4], -0.80901699437494742410f, 0.58778525229247312917f);
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        {
+            a[k] = pk_add(e[k], o[k]);
+            a[k + 5] = pk_sub(e[k], o[k]);
+        }
+}
+// w^k, k < 10, from w (a seed per butterfly)
+static __device__ __forceinline__ void pk_powers10(PkC w, PkC* tw)
+{
+    tw[0] = PkC{psplat(1.0f), psplat(0.0f)};
+    tw[1] = w;
+#pragma unroll
+    for (int k = 2; k < 10; k++) tw[k] = (k % 2 == 0) ? pk_mul(tw[k / 2], tw[k / 2]) : pk_mul(tw[k - 1], w);
+}
+
+#ifndef ACQ_ROWS3_WAVES
+#define ACQ_ROWS3_WAVES 4
+#endif
+template <bool INV>
+__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
+{
+    constexpr int R = 10, N2 = 1000, NB = N2 / R, NP = NB / 2;
+    extern __shared__ float2 sm[];
+    float* pre = reinterpret_cast<float*>(sm);  // plane of real parts: rpw rows of N2
+    float* pim = pre + g.rpw * N2;              // plane of imaginary parts
+    const int per_xcd = gridDim.x >> 3;
+    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (group >= g.n_groups) return;
+    const int row0 = group * g.rpw;
+    const int nrow = min(g.rpw, g.n_rows - row0);
+    const int N = plan.N, N1 = plan.N1;
+    const int p = threadIdx.x;
+    const bool act = p < nrow * NP;
+    const int row = act ? p / NP : 0;
+    const int u = 2 * (p - row * NP);  // even butterfly of the pair, 0 .. 98
+    int cell, k1, bin, sat;
+    {
+        const float inv_n1 = 1.0f / (float)N1, inv_ns = 1.0f / (float)g.n_sats;
+        const int rowid = row0 + row;
+        if (g.sat_fastest)
+            {
+                const int bk = fdiv(rowid, inv_ns);
+                sat = rowid - bk * g.n_sats;
+                bin = fdiv(bk, inv_n1);
+                k1 = bk - bin * N1;
+            }
+        else
+            {
+                const int cl = fdiv(rowid, inv_n1);
+                k1 = rowid - cl * N1;
+                bin = fdiv(cl, inv_ns);
+                sat = cl - bin * g.n_sats;
+            }
+        cell = sat * g.n_bins + bin;
+    }
+    PkC a[R], tw[R];
+    // ---- stage 1: S = 1, M = 100; butterflies q = u, u + 1; inputs x[q + 100 j] from global memory (x the code spectrum) ----
+    if (act)
+        {
+            const acq_f32x4 sd = *reinterpret_cast<const acq_f32x4*>(g.wN2 + plan.tw_off[0] + u);  // w_1000^u, w_1000^(u+1)
+            const float2* ap = g.A + (size_t)bin * N + (size_t)k1 * N2 + u;
+            if (g.B)
+                {
+                    const float2* bp = g.B + (size_t)sat * N + (size_t)k1 * N2 + u;
+#pragma unroll
+                    for (int j = 0; j < R; j++)
+                        {
+                            const acq_f32x4 va = *reinterpret_cast<const acq_f32x4*>(ap + 100 * j);
+                            const acq_f32x4 vb = *reinterpret_cast<const acq_f32x4*>(bp + 100 * j);
+                            a[j] = pk_mul(PkC{acq_pk2{va.x, va.z}, acq_pk2{va.y, va.w}}, PkC{acq_pk2{vb.x, vb.z}, acq_pk2{vb.y, vb.w}});
+                        }
+                }
+            else
+                {
+#pragma unroll
+                    for (int j = 0; j < R; j++)
+                        {
+                            const acq_f32x4 va = *reinterpret_cast<const acq_f32x4*>(ap + 100 * j);
+                            a[j] = PkC{acq_pk2{va.x, va.z}, acq_pk2{va.y, va.w}};
+                        }
+                }
+            pk_dft10<INV>(a);
+            pk_powers10(PkC{acq_pk2{sd.x, sd.z}, acq_pk2{sd.y, sd.w}}, tw);
+#pragma unroll
+            for (int k = 1; k < R; k++) a[k] = pk_tmul<INV>(a[k], tw[k]);
+            // butterfly q writes y[10 q + k]: the pair's 20 outputs are contiguous in each plane
+            float* yr = pre + row * N2 + R * u;
+            float* yi = pim + row * N2 + R * u;
+#pragma unroll
+            for (int k = 0; k < R; k += 2)
+                {
+                    *reinterpret_cast<acq_pk2*>(yr + k) = acq_pk2{a[k].r.x, a[k + 1].r.x};
+                    *reinterpret_cast<acq_pk2*>(yi + k) = acq_pk2{a[k].i.x, a[k + 1].i.x};
+                    *reinterpret_cast<acq_pk2*>(yr + R + k) = acq_pk2{a[k].r.y, a[k + 1].r.y};
+                    *reinterpret_cast<acq_pk2*>(yi + R + k) = acq_pk2{a[k].i.y, a[k + 1].i.y};
+                }
+        }
+    __syncthreads();
+    // ---- stage 2: S = 10, M = 10; u = 10 q + r, the pair shares q; inputs x[r + 10 q + 100 j] ----
+    {
+        const int q = u / 10, r = u - 10 * q;
+        float2 sd = make_float2(1.f, 0.f);
+        if (act)
+            {
+                sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
+                const float* xr = pre + row * N2 + u;
+                const float* xi = pim + row * N2 + u;
+#pragma unroll
+                for (int j = 0; j < R; j++) a[j] = PkC{*reinterpret_cast<const acq_pk2*>(xr + 100 * j), *reinterpret_cast<const acq_pk2*>(xi + 100 * j)};
+            }
+        __syncthreads();  // every input of this stage has left LDS
+        if (act)
+            {
+                pk_dft10<INV>(a);
+                pk_powers10(PkC{psplat(sd.x), psplat(sd.y)}, tw);
+                float* yr = pre + row * N2 + r + 100 * q;
+                float* yi = pim + row * N2 + r + 100 * q;
+                *reinterpret_cast<acq_pk2*>(yr) = a[0].r;
+                *reinterpret_cast<acq_pk2*>(yi) = a[0].i;
+#pragma unroll
+                for (int k = 1; k < R; k++)
+                    {
+                        const PkC o = pk_tmul<INV>(a[k], tw[k]);
+                        *reinterpret_cast<acq_pk2*>(yr + 10 * k) = o.r;
+                        *reinterpret_cast<acq_pk2*>(yi + 10 * k) = o.i;
+                    }
+            }
+        __syncthreads();
+    }
+    // ---- stage 3: S = 100, M = 1; r = u; inputs x[r + 100 j]; outputs n2 = r + 100 k with the inter-pass twiddle ----
+    if (act)
+        {
+            const acq_f32x4 b = *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);  // w_N^(k1 r), w_N^(k1 (r + 1))
+            const float2 d = g.wN[(size_t)k1 * N2 + 100];                                          // w_N^(100 k1)
+            const float* xr = pre + row * N2 + u;
+            const float* xi = pim + row * N2 + u;
+#pragma unroll
+            for (int j = 0; j < R; j++) a[j] = PkC{*reinterpret_cast<const acq_pk2*>(xr + 100 * j), *reinterpret_cast<const acq_pk2*>(xi + 100 * j)};
+            pk_dft10<INV>(a);
+            pk_powers10(PkC{psplat(d.x), psplat(d.y)}, tw);
+            const PkC bb = {acq_pk2{b.x, b.z}, acq_pk2{b.y, b.w}};
+            float2* qp = g.Q + (size_t)cell * N + (size_t)k1 * N2 + u;
+#pragma unroll
+            for (int k = 0; k < R; k++)
+                {
+                    const PkC o = pk_tmul<INV>(a[k], k == 0 ? bb : pk_mul(bb, tw[k]));
+                    *reinterpret_cast<acq_f32x4*>(qp + 100 * k) = acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y};
+                }
+        }
+}
+
 // stage list: RI = R*16 + ITER per stage, run in order
 template <bool INV, int N2, int S, int F, int... RI>
 struct Rows2Run;
@@ -775,7 +986,7 @@ struct AcqRows2Entry
 #define ROWS2_ENTRY4(a, b, c, d) {4, {a, b, c, d}, &acq_rows2_kernel<false, a, b, c, d>, &acq_rows2_kernel<true, a, b, c, d>, nullptr, nullptr}
 static const AcqRows2Entry acq_rows2_registry[] = {
     {3, {R2(10, 2), R2(10, 2), R2(10, 2), 0}, &acq_rows2_kernel<false, R2(10, 2), R2(10, 2), R2(10, 2)>, &acq_rows2_kernel<true, R2(10, 2), R2(10, 2), R2(10, 2)>,
-        &acq_rows2p_kernel<false, 10, 10, 10>, &acq_rows2p_kernel<true, 10, 10, 10>},  // 1000: N = 2000 ... 25000
+        &acq_rows3_kernel<false>, &acq_rows3_kernel<true>},  // 1000: N = 2000 ... 25000 (planar pair kernel)
     ROWS2_ENTRY3(R2(10, 1), R2(10, 1), R2(10, 1)),            // 1000, at most 2 rows per workgroup
     ROWS2_ENTRY3(R2(16, 1), R2(16, 1), R2(4, 4)),             // 1024
     ROWS2_ENTRY4(R2(10, 2), R2(5, 4), R2(5, 4), R2(5, 4)),    // 1250: N = 2500, 6250, 12500
@@ -1528,6 +1739,12 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             }();
             AcqRows2Fn fn = inverse ? entry->inv : entry->fwd;
             if (!no_pairs && entry->pair_fwd) fn = inverse ? entry->pair_inv : entry->pair_fwd;
+            static const bool interleaved_pairs = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
+                return e && std::strcmp(e, "pair2p") == 0;  // A/B knob: the pair kernel with (re, im) packing
+            }();
+            if (interleaved_pairs && entry->pair_fwd)
+                fn = inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<true, 10, 10, 10>) : reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<false, 10, 10, 10>);
             static const int row_order = [] {
                 const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");  // A/B knob: 0 = (bin, sat, k1), 1 = (bin, k1, sat)
                 return e ? std::atoi(e) : 1;

@@ -609,20 +609,20 @@ struct L1Request
     int n_corr = 0, mode = 0, fmt = 0, n_slices = 1, lds_floats = 0;
     const char* host_sig = nullptr;    // caller's sig_in
     size_t sig_bytes = 0;
-    // where the window is read from: (a) a registered host region (region >= 0: no staging copy, device view reg_dev), or
-    // (b) this request's page-locked copy (pinned_sig / its device view in chan.iq), or (c) the copy of an EARLIER request of the
-    // queue that handed in the same pointer (rep != NULL: this request copied nothing)
+    // where the window is read from: (a) a registered host region (region >= 0: no staging copy, device view reg_dev); (b) this
+    // request's page-locked copy (self_copied: made by the calling thread before it queued, in parallel with the others);
+    // (c) deferred: the request overlapped an earlier queued one when it arrived and copied nothing -- the leader of its batch
+    // stages the UNION of overlapping windows once (channels read neighbouring positions of one stream buffer)
     int region = -1;
     const char* reg_dev = nullptr;
-    const void* pinned_sig = nullptr;
-    L1Request* rep = nullptr;
-    bool copy_done = false;
+    const void* own_dev = nullptr;   // device view of this request's page-locked buffer
+    bool self_copied = false;
+    bool copy_done = false;          // queued and ready to be taken
     void* out_host = nullptr;
     size_t out_bytes = 0;
     gc_status status = GC_OK;
     char err[200] = "";
     bool taken = false;
-    bool orphan = false;               // its representative went into a batch without it: the owner fetches the window itself
     std::atomic<bool> done{false};     // set last by the batch's leader; the owner returns on it without taking any lock
     std::shared_ptr<L1Waiter> waiter;  // the owner thread's
 };
@@ -639,6 +639,9 @@ struct L1Lane
     float2* d_partial = nullptr;
     char* d_span = nullptr;              // windows shared by several requests of a batch, copied once
     size_t span_cap = 0;
+    char* h_span = nullptr;              // page-locked, mapped: where the leader stages unions of overlapping unregistered windows
+    const char* dv_span = nullptr;       // its device view
+    size_t hspan_cap = 0;
     bool busy = false;
 };
 
@@ -685,10 +688,14 @@ static void l1_batcher_free(void* p)
             if (l.h_out) (void)hipHostFree(l.h_out);
             (void)hipFree(l.d_partial);
             (void)hipFree(l.d_span);
+            if (l.h_span) (void)hipHostFree(l.h_span);
         }
     for (auto& r : b->regions) (void)hipHostUnregister(const_cast<char*>(r.host));
     delete b;
 }
+
+static bool l1_span_reserve(L1Lane& lane, size_t need);
+static bool l1_hspan_reserve(L1Lane& lane, size_t need);
 
 // the context's batcher (created by the first caller; NULL if its buffers cannot be set up: callers then use the direct path)
 static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
@@ -714,6 +721,9 @@ static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
             ok = ok && hipHostGetDevicePointer(&dv, l.h_out, 0) == hipSuccess;
             l.dv_out = static_cast<float2*>(dv);
             ok = ok && hipMalloc(&l.d_partial, sizeof(float2) * GC_MAX_TAPS * gc_l1_batcher::MAX_SLICES * gc_l1_batcher::MAXB) == hipSuccess;
+            // the span buffers of a typical batch up front (page-locking megabytes takes milliseconds: not inside a call)
+            if (ok) (void)l1_span_reserve(l, (size_t)8 << 20);
+            if (ok) (void)l1_hspan_reserve(l, (size_t)8 << 20);
         }
     if (!ok) (void)hipGetLastError();
     b->ok = ok;
@@ -757,6 +767,26 @@ static bool l1_span_reserve(L1Lane& lane, size_t need)
     return true;
 }
 
+static bool l1_hspan_reserve(L1Lane& lane, size_t need)
+{
+    if (need <= lane.hspan_cap) return true;
+    if (lane.h_span) (void)hipHostFree(lane.h_span);
+    lane.h_span = nullptr;
+    lane.hspan_cap = 0;
+    need = (need + ((size_t)4 << 20)) & ~(((size_t)1 << 20) - 1);  // page-locking is slow: grow in large steps
+    void* dv = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&lane.h_span), need, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dv, lane.h_span, 0) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            if (lane.h_span) (void)hipHostFree(lane.h_span);
+            lane.h_span = nullptr;
+            return false;
+        }
+    lane.dv_span = static_cast<const char*>(dv);
+    lane.hspan_cap = need;
+    return true;
+}
+
 // runs one batch on `lane` (no lock held); fills status / err of every request
 static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>& batch, const std::vector<L1Region>& regions, int* n_shared_out)
 {
@@ -769,13 +799,18 @@ static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>
     hipError_t e = hipSuccess;
     int n_shared = 0;
     size_t span_off = 0;
-    // room for every shared window of this batch, reserved before any pointer into the buffer is handed out
-    bool can_share = false;
+    // room for every shared window of this batch, reserved before any pointer into the buffers is handed out
+    bool can_share = false, can_stage = false;
     {
-        size_t need = 0;
+        size_t need = 0, need_host = 0;
         for (L1Request* r : batch)
-            if (r->sig_bytes > 0 && (r->region >= 0 || r->rep == nullptr)) need += r->sig_bytes + 512;
+            if (r->sig_bytes > 0)
+                {
+                    need += r->sig_bytes + 512;
+                    if (r->region < 0) need_host += r->sig_bytes + 512;
+                }
         can_share = l1_span_reserve(lane, need);
+        can_stage = need_host == 0 || l1_hspan_reserve(lane, need_host);
     }
     // (1) windows inside a registered host region: the callers' windows of one region overlap when the channels read
     // neighbouring positions of one stream buffer.  When the union of the windows is clearly smaller than their sum, the union
@@ -811,27 +846,72 @@ static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>
                     }
             span_off = off + uni;
         }
-    // (2) unregistered input: callers that handed in the SAME pointer share the first arrival's page-locked copy (rep);
-    // one DMA of it into HBM serves the whole group.  A caller's input is stable for the duration of its synchronous call
-    // and all of these calls are in progress now, so the bytes are the same for every member of the group.
-    for (int i = 0; i < B && e == hipSuccess; i++)
-        {
-            L1Request* rep = batch[i];
-            if (rep->region >= 0 || rep->rep != nullptr || rep->sig_bytes == 0) continue;
-            int followers = 0;
-            for (L1Request* r : batch) followers += (r->rep == rep);
-            if (!followers) continue;
-            const size_t off = (span_off + 255) & ~(size_t)255;
-            if (can_share && off + rep->sig_bytes <= lane.span_cap)
-                {
-                    e = l1_copy(lane.stream, rep->chan.iq /* device view of its page-locked copy */, lane.d_span + off, rep->sig_bytes);
-                    rep->chan.iq = lane.d_span + off;
-                    span_off = off + rep->sig_bytes;
-                }
-            for (L1Request* r : batch)
-                if (r->rep == rep) r->chan.iq = rep->chan.iq;  // the HBM copy, or the representative's page-locked buffer
-            n_shared += followers + 1;
-        }
+    // (2) unregistered input.  A window staged by its own calling thread is read in place from that thread's page-locked buffer.
+    // Windows that overlap (identical pointers; channels at neighbouring read positions of one GNU Radio buffer) form a
+    // cluster: the leader copies the cluster's UNION once from the callers' memory -- every byte of it lies inside the window
+    // of some member, and every member is blocked in its synchronous call, so the memory is valid and stable -- into the lane's
+    // page-locked span, one copy kernel moves it into HBM and each member reads its piece there.
+    size_t hoff = 0;
+    {
+        std::vector<L1Request*> un;
+        for (L1Request* r : batch)
+            if (r->region < 0 && r->sig_bytes > 0) un.push_back(r);
+        std::sort(un.begin(), un.end(), [](const L1Request* a, const L1Request* c) { return a->host_sig < c->host_sig; });
+        for (size_t i = 0; i < un.size() && e == hipSuccess;)
+            {
+                size_t j = i + 1;
+                const char* lo = un[i]->host_sig;
+                const char* hi = lo + un[i]->sig_bytes;
+                size_t sum = un[i]->sig_bytes;
+                bool any_deferred = !un[i]->self_copied;
+                while (j < un.size() && un[j]->host_sig <= hi)
+                    {
+                        hi = std::max(hi, un[j]->host_sig + un[j]->sig_bytes);
+                        sum += un[j]->sig_bytes;
+                        any_deferred |= !un[j]->self_copied;
+                        j++;
+                    }
+                const size_t uni = (size_t)(hi - lo), lead = (uintptr_t)lo & 15;
+                const bool cluster = (j - i >= 2) && (any_deferred || uni * 3 <= sum * 2);
+                if ((cluster || any_deferred) && !can_stage)
+                    {
+                        e = hipErrorOutOfMemory;
+                        break;
+                    }
+                if (cluster)
+                    {
+                        const size_t off = (hoff + 255) & ~(size_t)255;
+                        std::memcpy(lane.h_span + off + lead, lo, uni);
+                        hoff = off + lead + uni;
+                        const size_t doff = (span_off + 255) & ~(size_t)255;
+                        if (can_share && doff + lead + uni <= lane.span_cap)
+                            {
+                                e = l1_copy(lane.stream, lane.dv_span + off, lane.d_span + doff, lead + uni);
+                                for (size_t t = i; t < j; t++) un[t]->chan.iq = lane.d_span + doff + lead + (un[t]->host_sig - lo);
+                                span_off = doff + lead + uni;
+                            }
+                        else
+                            for (size_t t = i; t < j; t++) un[t]->chan.iq = lane.dv_span + off + lead + (un[t]->host_sig - lo);  // read in place over PCIe
+                        n_shared += (int)(j - i);
+                    }
+                else
+                    for (size_t t = i; t < j; t++)
+                        {
+                            L1Request* r = un[t];
+                            if (r->self_copied)
+                                r->chan.iq = r->own_dev;
+                            else
+                                {
+                                    // deferred, but what it overlapped went into another batch: the leader stages this window
+                                    const size_t off = (hoff + 255) & ~(size_t)255, ld = (uintptr_t)r->host_sig & 15;
+                                    std::memcpy(lane.h_span + off + ld, r->host_sig, r->sig_bytes);
+                                    hoff = off + ld + r->sig_bytes;
+                                    r->chan.iq = lane.dv_span + off + ld;
+                                }
+                        }
+                i = j;
+            }
+    }
     for (int i = 0; i < B; i++)
         {
             lane.h_chans[i] = batch[i]->chan;
@@ -869,7 +949,7 @@ static bool l1_same_shape(const L1Request* a, const L1Request* b)
 }
 
 // a request the next leader can take: its window is in place (own copy finished, or a registered region)
-static bool l1_ready(const L1Request* r) { return !r->taken && r->copy_done && r->rep == nullptr && !r->orphan; }
+static bool l1_ready(const L1Request* r) { return !r->taken && r->copy_done; }
 
 static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, const void* own_pinned_dev)
 {
@@ -896,18 +976,21 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, co
                     break;
                 }
         }
+    rq->own_dev = own_pinned_dev;
     if (rq->region < 0 && rq->sig_bytes > 0)
         {
-            // an earlier, still queued call with the same input pointer (and kernel shape) has the window in its page-locked
-            // buffer already, or is copying it right now: follow it instead of copying the same bytes again
+            // an earlier, still queued call of the same kernel shape whose window overlaps this one: copy nothing, the leader of
+            // the batch stages the union once
             for (L1Request* r : b->queue)
-                if (!r->taken && r->rep == nullptr && r->region < 0 && r->host_sig == rq->host_sig && r->sig_bytes >= rq->sig_bytes && l1_same_shape(r, rq))
+                if (!r->taken && r->region < 0 && r->sig_bytes > 0 && l1_same_shape(r, rq) && rq->host_sig < r->host_sig + r->sig_bytes &&
+                    r->host_sig < rq->host_sig + rq->sig_bytes)
                     {
-                        rq->rep = r;
                         rq->copy_done = true;
                         break;
                     }
         }
+    else
+        rq->copy_done = true;
     b->queue.push_back(rq);
     bool need_copy = !rq->copy_done;
     for (;;)
@@ -917,19 +1000,11 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, co
                     lk.unlock();
                     if (rq->sig_bytes > 0) std::memcpy(own_pinned, rq->host_sig, rq->sig_bytes);
                     lk.lock();
-                    rq->pinned_sig = own_pinned;
-                    rq->chan.iq = own_pinned_dev;
+                    rq->self_copied = true;
                     rq->copy_done = true;
                     need_copy = false;
                 }
             if (rq->done.load(std::memory_order_acquire)) break;
-            if (rq->orphan)
-                {
-                    // the call this one followed went into a batch without it (the batch was full): fetch the window itself
-                    rq->orphan = false;
-                    need_copy = true;
-                    continue;
-                }
             L1Lane* lane = nullptr;
             if (!rq->taken)
                 for (auto& l : b->lanes)
@@ -965,15 +1040,12 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, co
                     lk.lock();
                     continue;
                 }
-            // lead: everything queued right now with the shape of the oldest ready request -- the requests whose window is in
-            // place, and the followers of those (a follower sits behind its representative in the queue)
+            // lead: everything queued right now with the shape of the oldest ready request
             std::vector<L1Request*> batch;
             for (auto it = b->queue.begin(); it != b->queue.end() && (int)batch.size() < gc_l1_batcher::MAXB;)
                 {
                     L1Request* r = *it;
-                    bool take = !r->taken && l1_same_shape(r, key) && r->copy_done;
-                    if (take && r->rep != nullptr) take = std::find(batch.begin(), batch.end(), r->rep) != batch.end();
-                    if (take)
+                    if (!r->taken && r->copy_done && l1_same_shape(r, key))
                         {
                             r->taken = true;
                             batch.push_back(r);
@@ -982,20 +1054,9 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, co
                     else
                         ++it;
                 }
-            // followers left behind by a full batch are detached now, while their representative is certainly alive
-            std::vector<std::shared_ptr<L1Waiter>> orphans;
-            for (L1Request* r : b->queue)
-                if (r->rep != nullptr && r->rep->taken)
-                    {
-                        r->rep = nullptr;
-                        r->copy_done = false;
-                        r->orphan = true;
-                        if (r != rq) orphans.push_back(r->waiter);
-                    }
             const std::vector<L1Region> regions = b->regions;
             lane->busy = true;
             lk.unlock();
-            for (auto& w : orphans) w->signal();
             int n_shared = 0;
             l1_run_batch(b, *lane, batch, regions, &n_shared);
             lk.lock();

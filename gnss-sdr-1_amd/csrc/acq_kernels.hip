@@ -374,6 +374,8 @@ struct AcqRows2Args
     int n_sats;  // satellites in this launch; cell = sat * n_bins + bin
     int n_groups;  // workgroups that have rows
     int sat_fastest;  // pair kernel: row order (bin, k1, sat) instead of (bin, sat, k1)
+    int dbg;          // $GNSSCORR_ACQ_DBG, timing experiments on acq_rows3_kernel only (results are WRONG with any bit set):
+                      // 1 = no global input loads, 2 = no global stores, 4 = no twiddle loads, 8 = no butterflies
 };
 
 // floor(a / b) for 0 <= a < 2^22 given inv_b = 1.0f / b
@@ -792,20 +794,26 @@ static __device__ __forceinline__ void pk_powers10(PkC w, PkC* tw)
 #ifndef ACQ_ROWS3_WAVES
 #define ACQ_ROWS3_WAVES 4
 #endif
-template <bool INV>
-__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
+template <bool INV, int THREADS = ACQ_THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
 {
     constexpr int R = 10, N2 = 1000, NB = N2 / R, NP = NB / 2;
     extern __shared__ float2 sm[];
     float* pre = reinterpret_cast<float*>(sm);  // plane of real parts: rpw rows of N2
     float* pim = pre + g.rpw * N2;              // plane of imaginary parts
-    const int per_xcd = gridDim.x >> 3;
-    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (group >= g.n_groups) return;
-    const int row0 = group * g.rpw;
-    const int nrow = min(g.rpw, g.n_rows - row0);
+    // Each XCD owns one contiguous eighth of the row groups (blocks with equal blockIdx % 8 share an L2); a workgroup walks its
+    // XCD's groups with the stride of the launch: once when the grid has a block per group, several times when the launch is
+    // sized to the chip (persistent form: the stores of one group drain behind the loads of the next instead of at the wave's end)
+    const int wg_per_xcd = gridDim.x >> 3;
+    const int groups_per_xcd = (g.n_groups + 7) >> 3;
     const int N = plan.N, N1 = plan.N1;
     const int p = threadIdx.x;
+    for (int gi = blockIdx.x >> 3; gi < groups_per_xcd; gi += wg_per_xcd)
+    {
+    const int group = (blockIdx.x & 7) * groups_per_xcd + gi;
+    if (group >= g.n_groups) break;
+    const int row0 = group * g.rpw;
+    const int nrow = min(g.rpw, g.n_rows - row0);
     const bool act = p < nrow * NP;
     const int row = act ? p / NP : 0;
     const int u = 2 * (p - row * NP);  // even butterfly of the pair, 0 .. 98
@@ -833,9 +841,14 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
     // ---- stage 1: S = 1, M = 100; butterflies q = u, u + 1; inputs x[q + 100 j] from global memory (x the code spectrum) ----
     if (act)
         {
-            const acq_f32x4 sd = *reinterpret_cast<const acq_f32x4*>(g.wN2 + plan.tw_off[0] + u);  // w_1000^u, w_1000^(u+1)
+            const acq_f32x4 sd = (g.dbg & 4) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN2 + plan.tw_off[0] + u);  // w_1000^u, w_1000^(u+1)
             const float2* ap = g.A + (size_t)bin * N + (size_t)k1 * N2 + u;
-            if (g.B)
+            if (g.dbg & 1)
+                {
+#pragma unroll
+                    for (int j = 0; j < R; j++) a[j] = PkC{acq_pk2{(float)(u + j), 1.0f}, acq_pk2{0.5f, (float)j}};
+                }
+            else if (g.B)
                 {
                     const float2* bp = g.B + (size_t)sat * N + (size_t)k1 * N2 + u;
 #pragma unroll
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
                             a[j] = PkC{acq_pk2{va.x, va.z}, acq_pk2{va.y, va.w}};
                         }
                 }
-            pk_dft10<INV>(a);
+            if (!(g.dbg & 8)) pk_dft10<INV>(a);
             pk_powers10(PkC{acq_pk2{sd.x, sd.z}, acq_pk2{sd.y, sd.w}}, tw);
 #pragma unroll
             for (int k = 1; k < R; k++) a[k] = pk_tmul<INV>(a[k], tw[k]);
@@ -878,7 +891,7 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
         float2 sd = make_float2(1.f, 0.f);
         if (act)
             {
-                sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
+                if (!(g.dbg & 4)) sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
                 const float* xr = pre + row * N2 + u;
                 const float* xi = pim + row * N2 + u;
 #pragma unroll
@@ -887,7 +900,7 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
         __syncthreads();  // every input of this stage has left LDS
         if (act)
             {
-                pk_dft10<INV>(a);
+                if (!(g.dbg & 8)) pk_dft10<INV>(a);
                 pk_powers10(PkC{psplat(sd.x), psplat(sd.y)}, tw);
                 float* yr = pre + row * N2 + r + 100 * q;
                 float* yi = pim + row * N2 + r + 100 * q;
@@ -906,13 +919,13 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
     // ---- stage 3: S = 100, M = 1; r = u; inputs x[r + 100 j]; outputs n2 = r + 100 k with the inter-pass twiddle ----
     if (act)
         {
-            const acq_f32x4 b = *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);  // w_N^(k1 r), w_N^(k1 (r + 1))
-            const float2 d = g.wN[(size_t)k1 * N2 + 100];                                          // w_N^(100 k1)
+            const acq_f32x4 b = (g.dbg & 4) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);  // w_N^(k1 r), w_N^(k1 (r + 1))
+            const float2 d = (g.dbg & 4) ? make_float2(1.f, 0.f) : g.wN[(size_t)k1 * N2 + 100];                                          // w_N^(100 k1)
             const float* xr = pre + row * N2 + u;
             const float* xi = pim + row * N2 + u;
 #pragma unroll
             for (int j = 0; j < R; j++) a[j] = PkC{*reinterpret_cast<const acq_pk2*>(xr + 100 * j), *reinterpret_cast<const acq_pk2*>(xi + 100 * j)};
-            pk_dft10<INV>(a);
+            if (!(g.dbg & 8)) pk_dft10<INV>(a);
             pk_powers10(PkC{psplat(d.x), psplat(d.y)}, tw);
             const PkC bb = {acq_pk2{b.x, b.z}, acq_pk2{b.y, b.w}};
             float2* qp = g.Q + (size_t)cell * N + (size_t)k1 * N2 + u;
@@ -920,9 +933,11 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
             for (int k = 0; k < R; k++)
                 {
                     const PkC o = pk_tmul<INV>(a[k], k == 0 ? bb : pk_mul(bb, tw[k]));
-                    *reinterpret_cast<acq_f32x4*>(qp + 100 * k) = acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y};
+                    if (!(g.dbg & 2) || o.r.x == 1.2345e-33f) *reinterpret_cast<acq_f32x4*>(qp + 100 * k) = acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y};
                 }
         }
+    __syncthreads();  // stage 3 has read the planes: the next group's stage 1 may overwrite them
+    }
 }
 
 // stage list: RI = R*16 + ITER per stage, run in order
@@ -1745,11 +1760,37 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             }();
             if (interleaved_pairs && entry->pair_fwd)
                 fn = inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<true, 10, 10, 10>) : reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<false, 10, 10, 10>);
+            static const bool wave_rows = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
+                return e && std::strcmp(e, "wave") == 0;  // experiment: one row per single-wave workgroup (no workgroup barriers)
+            }();
+            if (wave_rows && entry->pair_fwd && plan.N2 == 1000)
+                {
+                    g.rpw = 1;
+                    g.n_groups = g.n_rows;
+                    dim3 gridw((unsigned)((g.n_groups + 7) / 8 * 8));
+                    fn = inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows3_kernel<true, 64>) : reinterpret_cast<AcqRows2Fn>(&acq_rows3_kernel<false, 64>);
+                    return hipLaunchKernel(reinterpret_cast<const void*>(fn), gridw, dim3(64), args, (size_t)plan.N2 * sizeof(float2), st);
+                }
             static const int row_order = [] {
                 const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");  // A/B knob: 0 = (bin, sat, k1), 1 = (bin, k1, sat)
                 return e ? std::atoi(e) : 1;
             }();
             g.sat_fastest = (B != nullptr && g.n_sats > 1) ? row_order : 0;
+            static const int dbg = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_DBG");
+                return e ? std::atoi(e) : 0;
+            }();
+            g.dbg = dbg;
+            static const int persist = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_PERSIST");  // workgroups per CU of the persistent row launch (0: one block per group)
+                return e ? std::atoi(e) : 4;  // measured: 4 per CU (what the LDS admits) is 2 % faster than a block per group
+            }();
+            if (persist > 0 && entry->pair_fwd && fn == (inverse ? entry->pair_inv : entry->pair_fwd))
+                {
+                    const unsigned cap = (unsigned)(persist * 256);
+                    if (grid2.x > cap) grid2.x = cap;
+                }
             return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);
         }
     dim3 grid(plan.N1, n_cells);

@@ -724,51 +724,66 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS2P_WAVES) void acq_rows2p_kern
 // apart: its disassembly has 250 register moves among 1148 VALU instructions per wave.  LDS holds the rows as two planes (re,
 // im) so that a pair's inputs and outputs of the LDS stages are 8-byte accesses of one plane each.
 typedef float acq_pk2 __attribute__((ext_vector_type(2)));
+// the planar complex arithmetic below is written once for a value type V: acq_pk2 (a pair of butterflies per thread, packed
+// instructions) or float (one butterfly per thread)
 static __device__ __forceinline__ acq_pk2 pfma(acq_pk2 a, acq_pk2 b, acq_pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+static __device__ __forceinline__ float pfma(float a, float b, float c) { return fmaf(a, b, c); }
+template <class V>
+static __device__ __forceinline__ V vsplat(float c);
+template <>
+__device__ __forceinline__ acq_pk2 vsplat<acq_pk2>(float c) { return acq_pk2{c, c}; }
+template <>
+__device__ __forceinline__ float vsplat<float>(float c) { return c; }
 static __device__ __forceinline__ acq_pk2 psplat(float c) { return acq_pk2{c, c}; }
-struct PkC  // a complex value per butterfly of the pair
+template <class V>
+struct VC  // a complex value per butterfly held by the thread
 {
-    acq_pk2 r, i;
+    V r, i;
 };
-static __device__ __forceinline__ PkC pk_mul(PkC a, PkC b) { return PkC{pfma(a.r, b.r, -(a.i * b.i)), pfma(a.r, b.i, a.i * b.r)}; }
-static __device__ __forceinline__ PkC pk_mul_conj(PkC a, PkC b) { return PkC{pfma(a.r, b.r, a.i * b.i), pfma(a.i, b.r, -(a.r * b.i))}; }
-template <bool INV>
-static __device__ __forceinline__ PkC pk_tmul(PkC a, PkC w) { return INV ? pk_mul_conj(a, w) : pk_mul(a, w); }
-static __device__ __forceinline__ PkC pk_add(PkC a, PkC b) { return PkC{a.r + b.r, a.i + b.i}; }
-static __device__ __forceinline__ PkC pk_sub(PkC a, PkC b) { return PkC{a.r - b.r, a.i - b.i}; }
+typedef VC<acq_pk2> PkC;
+template <class V>
+static __device__ __forceinline__ VC<V> pk_mul(VC<V> a, VC<V> b) { return VC<V>{pfma(a.r, b.r, -(a.i * b.i)), pfma(a.r, b.i, a.i * b.r)}; }
+template <class V>
+static __device__ __forceinline__ VC<V> pk_mul_conj(VC<V> a, VC<V> b) { return VC<V>{pfma(a.r, b.r, a.i * b.i), pfma(a.i, b.r, -(a.r * b.i))}; }
+template <bool INV, class V>
+static __device__ __forceinline__ VC<V> pk_tmul(VC<V> a, VC<V> w) { return INV ? pk_mul_conj(a, w) : pk_mul(a, w); }
+template <class V>
+static __device__ __forceinline__ VC<V> pk_add(VC<V> a, VC<V> b) { return VC<V>{a.r + b.r, a.i + b.i}; }
+template <class V>
+static __device__ __forceinline__ VC<V> pk_sub(VC<V> a, VC<V> b) { return VC<V>{a.r - b.r, a.i - b.i}; }
 // a + (-j) b (forward) / a + j b (inverse), and the same with the opposite sign of b
-template <bool INV>
-static __device__ __forceinline__ PkC pk_add_mj(PkC a, PkC b) { return INV ? PkC{a.r - b.i, a.i + b.r} : PkC{a.r + b.i, a.i - b.r}; }
-template <bool INV>
-static __device__ __forceinline__ PkC pk_sub_mj(PkC a, PkC b) { return INV ? PkC{a.r + b.i, a.i - b.r} : PkC{a.r - b.i, a.i + b.r}; }
+template <bool INV, class V>
+static __device__ __forceinline__ VC<V> pk_add_mj(VC<V> a, VC<V> b) { return INV ? VC<V>{a.r - b.i, a.i + b.r} : VC<V>{a.r + b.i, a.i - b.r}; }
+template <bool INV, class V>
+static __device__ __forceinline__ VC<V> pk_sub_mj(VC<V> a, VC<V> b) { return INV ? VC<V>{a.r + b.i, a.i - b.r} : VC<V>{a.r - b.i, a.i + b.r}; }
 // a * exp(-+j phi) for a constant phi
-template <bool INV>
-static __device__ __forceinline__ PkC pk_mul_const(PkC a, float c, float sn)
+template <bool INV, class V>
+static __device__ __forceinline__ VC<V> pk_mul_const(VC<V> a, float c, float sn)
 {
-    const acq_pk2 cc = psplat(c), ss = psplat(sn);
-    return INV ? PkC{pfma(a.r, cc, -(a.i * ss)), pfma(a.i, cc, a.r * ss)} : PkC{pfma(a.r, cc, a.i * ss), pfma(a.i, cc, -(a.r * ss))};
+    const V cc = vsplat<V>(c), ss = vsplat<V>(sn);
+    return INV ? VC<V>{pfma(a.r, cc, -(a.i * ss)), pfma(a.i, cc, a.r * ss)} : VC<V>{pfma(a.r, cc, a.i * ss), pfma(a.i, cc, -(a.r * ss))};
 }
-template <bool INV>
-static __device__ __forceinline__ void pk_dft5(PkC* a)
+template <bool INV, class V>
+static __device__ __forceinline__ void pk_dft5(VC<V>* a)
 {
-    const acq_pk2 c1 = psplat(0.30901699437494742410f), c2 = psplat(-0.80901699437494742410f);
-    const acq_pk2 s1 = psplat(0.95105651629515357212f), s2 = psplat(0.58778525229247312917f);
-    const PkC t1 = pk_add(a[1], a[4]), t2 = pk_add(a[2], a[3]), t3 = pk_sub(a[1], a[4]), t4 = pk_sub(a[2], a[3]);
-    const PkC m1 = {pfma(c2, t2.r, pfma(c1, t1.r, a[0].r)), pfma(c2, t2.i, pfma(c1, t1.i, a[0].i))};
-    const PkC m2 = {pfma(c1, t2.r, pfma(c2, t1.r, a[0].r)), pfma(c1, t2.i, pfma(c2, t1.i, a[0].i))};
-    const PkC v1 = {pfma(s2, t4.r, s1 * t3.r), pfma(s2, t4.i, s1 * t3.i)};
-    const PkC v2 = {pfma(s2, t3.r, -(s1 * t4.r)), pfma(s2, t3.i, -(s1 * t4.i))};
+    const V c1 = vsplat<V>(0.30901699437494742410f), c2 = vsplat<V>(-0.80901699437494742410f);
+    const V s1 = vsplat<V>(0.95105651629515357212f), s2 = vsplat<V>(0.58778525229247312917f);
+    const VC<V> t1 = pk_add(a[1], a[4]), t2 = pk_add(a[2], a[3]), t3 = pk_sub(a[1], a[4]), t4 = pk_sub(a[2], a[3]);
+    const VC<V> m1 = {pfma(c2, t2.r, pfma(c1, t1.r, a[0].r)), pfma(c2, t2.i, pfma(c1, t1.i, a[0].i))};
+    const VC<V> m2 = {pfma(c1, t2.r, pfma(c2, t1.r, a[0].r)), pfma(c1, t2.i, pfma(c2, t1.i, a[0].i))};
+    const VC<V> v1 = {pfma(s2, t4.r, s1 * t3.r), pfma(s2, t4.i, s1 * t3.i)};
+    const VC<V> v2 = {pfma(s2, t3.r, -(s1 * t4.r)), pfma(s2, t3.i, -(s1 * t4.i))};
     a[0] = pk_add(a[0], pk_add(t1, t2));
     a[1] = pk_add_mj<INV>(m1, v1);
     a[4] = pk_sub_mj<INV>(m1, v1);
     a[2] = pk_add_mj<INV>(m2, v2);
     a[3] = pk_sub_mj<INV>(m2, v2);
 }
-template <bool INV>
-static __device__ __forceinline__ void pk_dft10(PkC* a)
+template <bool INV, class V>
+static __device__ __forceinline__ void pk_dft10(VC<V>* a)
 {
-    PkC e[5] = {a[0], a[2], a[4], a[6], a[8]};
-    PkC o[5] = {a[1], a[3], a[5], a[7], a[9]};
+    VC<V> e[5] = {a[0], a[2], a[4], a[6], a[8]};
+    VC<V> o[5] = {a[1], a[3], a[5], a[7], a[9]};
     pk_dft5<INV>(e);
     pk_dft5<INV>(o);
     o[1] = pk_mul_const<INV>(o[1], 0.80901699437494742410f, 0.58778525229247312917f);
@@ -783,19 +798,23 @@ static __device__ __forceinline__ void pk_dft10(PkC* a)
         }
 }
 // w^k, k < 10, from w (a seed per butterfly)
-static __device__ __forceinline__ void pk_powers10(PkC w, PkC* tw)
+template <class V>
+static __device__ __forceinline__ void pk_powers10(VC<V> w, VC<V>* tw)
 {
-    tw[0] = PkC{psplat(1.0f), psplat(0.0f)};
+    tw[0] = VC<V>{vsplat<V>(1.0f), vsplat<V>(0.0f)};
     tw[1] = w;
 #pragma unroll
     for (int k = 2; k < 10; k++) tw[k] = (k % 2 == 0) ? pk_mul(tw[k / 2], tw[k / 2]) : pk_mul(tw[k - 1], w);
 }
 
+#ifndef ACQ_ROWS3_DBG
+#define ACQ_ROWS3_DBG 0  // 1: compile the phase-elimination switches of $GNSSCORR_ACQ_DBG in (profiles/tools/rows3_phases.sh builds with it)
+#endif
 #ifndef ACQ_ROWS3_WAVES
 #define ACQ_ROWS3_WAVES 4
 #endif
-template <bool INV, int THREADS = ACQ_THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
+template <bool INV>
+__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
 {
     constexpr int R = 10, N2 = 1000, NB = N2 / R, NP = NB / 2;
     extern __shared__ float2 sm[];
@@ -808,6 +827,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void 
     const int groups_per_xcd = (g.n_groups + 7) >> 3;
     const int N = plan.N, N1 = plan.N1;
     const int p = threadIdx.x;
+#pragma nounroll
     for (int gi = blockIdx.x >> 3; gi < groups_per_xcd; gi += wg_per_xcd)
     {
     const int group = (blockIdx.x & 7) * groups_per_xcd + gi;
@@ -841,9 +861,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void 
     // ---- stage 1: S = 1, M = 100; butterflies q = u, u + 1; inputs x[q + 100 j] from global memory (x the code spectrum) ----
     if (act)
         {
-            const acq_f32x4 sd = (g.dbg & 4) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN2 + plan.tw_off[0] + u);  // w_1000^u, w_1000^(u+1)
+            const acq_f32x4 sd = (ACQ_ROWS3_DBG && (g.dbg & 4)) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN2 + plan.tw_off[0] + u);  // w_1000^u, w_1000^(u+1)
             const float2* ap = g.A + (size_t)bin * N + (size_t)k1 * N2 + u;
-            if (g.dbg & 1)
+            if (ACQ_ROWS3_DBG && (g.dbg & 1))
                 {
 #pragma unroll
                     for (int j = 0; j < R; j++) a[j] = PkC{acq_pk2{(float)(u + j), 1.0f}, acq_pk2{0.5f, (float)j}};
@@ -868,7 +888,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void 
                             a[j] = PkC{acq_pk2{va.x, va.z}, acq_pk2{va.y, va.w}};
                         }
                 }
-            if (!(g.dbg & 8)) pk_dft10<INV>(a);
+            if (!(ACQ_ROWS3_DBG && (g.dbg & 8))) pk_dft10<INV>(a);
             pk_powers10(PkC{acq_pk2{sd.x, sd.z}, acq_pk2{sd.y, sd.w}}, tw);
 #pragma unroll
             for (int k = 1; k < R; k++) a[k] = pk_tmul<INV>(a[k], tw[k]);
@@ -891,7 +911,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void 
         float2 sd = make_float2(1.f, 0.f);
         if (act)
             {
-                if (!(g.dbg & 4)) sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
+                if (!(ACQ_ROWS3_DBG && (g.dbg & 4))) sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
                 const float* xr = pre + row * N2 + u;
                 const float* xi = pim + row * N2 + u;
 #pragma unroll
@@ -900,7 +920,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void 
         __syncthreads();  // every input of this stage has left LDS
         if (act)
             {
-                if (!(g.dbg & 8)) pk_dft10<INV>(a);
+                if (!(ACQ_ROWS3_DBG && (g.dbg & 8))) pk_dft10<INV>(a);
                 pk_powers10(PkC{psplat(sd.x), psplat(sd.y)}, tw);
                 float* yr = pre + row * N2 + r + 100 * q;
                 float* yi = pim + row * N2 + r + 100 * q;
@@ -919,13 +939,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void 
     // ---- stage 3: S = 100, M = 1; r = u; inputs x[r + 100 j]; outputs n2 = r + 100 k with the inter-pass twiddle ----
     if (act)
         {
-            const acq_f32x4 b = (g.dbg & 4) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);  // w_N^(k1 r), w_N^(k1 (r + 1))
-            const float2 d = (g.dbg & 4) ? make_float2(1.f, 0.f) : g.wN[(size_t)k1 * N2 + 100];                                          // w_N^(100 k1)
+            const acq_f32x4 b = (ACQ_ROWS3_DBG && (g.dbg & 4)) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);  // w_N^(k1 r), w_N^(k1 (r + 1))
+            const float2 d = (ACQ_ROWS3_DBG && (g.dbg & 4)) ? make_float2(1.f, 0.f) : g.wN[(size_t)k1 * N2 + 100];                                          // w_N^(100 k1)
             const float* xr = pre + row * N2 + u;
             const float* xi = pim + row * N2 + u;
 #pragma unroll
             for (int j = 0; j < R; j++) a[j] = PkC{*reinterpret_cast<const acq_pk2*>(xr + 100 * j), *reinterpret_cast<const acq_pk2*>(xi + 100 * j)};
-            if (!(g.dbg & 8)) pk_dft10<INV>(a);
+            if (!(ACQ_ROWS3_DBG && (g.dbg & 8))) pk_dft10<INV>(a);
             pk_powers10(PkC{psplat(d.x), psplat(d.y)}, tw);
             const PkC bb = {acq_pk2{b.x, b.z}, acq_pk2{b.y, b.w}};
             float2* qp = g.Q + (size_t)cell * N + (size_t)k1 * N2 + u;
@@ -933,7 +953,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 5 : ACQ_ROWS3_WAVES) void 
             for (int k = 0; k < R; k++)
                 {
                     const PkC o = pk_tmul<INV>(a[k], k == 0 ? bb : pk_mul(bb, tw[k]));
-                    if (!(g.dbg & 2) || o.r.x == 1.2345e-33f) *reinterpret_cast<acq_f32x4*>(qp + 100 * k) = acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y};
+                    if (!(ACQ_ROWS3_DBG && (g.dbg & 2)) || o.r.x == 1.2345e-33f) *reinterpret_cast<acq_f32x4*>(qp + 100 * k) = acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y};
                 }
         }
     __syncthreads();  // stage 3 has read the planes: the next group's stage 1 may overwrite them
@@ -1760,37 +1780,6 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             }();
             if (interleaved_pairs && entry->pair_fwd)
                 fn = inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<true, 10, 10, 10>) : reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<false, 10, 10, 10>);
-            static const bool wave_rows = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
-                return e && std::strcmp(e, "wave") == 0;  // experiment: one row per single-wave workgroup (no workgroup barriers)
-            }();
-            if (wave_rows && entry->pair_fwd && plan.N2 == 1000)
-                {
-                    g.rpw = 1;
-                    g.n_groups = g.n_rows;
-                    dim3 gridw((unsigned)((g.n_groups + 7) / 8 * 8));
-                    fn = inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows3_kernel<true, 64>) : reinterpret_cast<AcqRows2Fn>(&acq_rows3_kernel<false, 64>);
-                    return hipLaunchKernel(reinterpret_cast<const void*>(fn), gridw, dim3(64), args, (size_t)plan.N2 * sizeof(float2), st);
-                }
-            static const int row_order = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");  // A/B knob: 0 = (bin, sat, k1), 1 = (bin, k1, sat)
-                return e ? std::atoi(e) : 1;
-            }();
-            g.sat_fastest = (B != nullptr && g.n_sats > 1) ? row_order : 0;
-            static const int dbg = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_DBG");
-                return e ? std::atoi(e) : 0;
-            }();
-            g.dbg = dbg;
-            static const int persist = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_PERSIST");  // workgroups per CU of the persistent row launch (0: one block per group)
-                return e ? std::atoi(e) : 4;  // measured: 4 per CU (what the LDS admits) is 2 % faster than a block per group
-            }();
-            if (persist > 0 && entry->pair_fwd && fn == (inverse ? entry->pair_inv : entry->pair_fwd))
-                {
-                    const unsigned cap = (unsigned)(persist * 256);
-                    if (grid2.x > cap) grid2.x = cap;
-                }
             return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);
         }
     dim3 grid(plan.N1, n_cells);

@@ -230,8 +230,12 @@ def main():
         real[str(prn)] = dict(indext=int(r.indext), doppler=int(r.doppler), test_statistics=float(r.test_statistics), mag=float(r.mag),
             input_power=float(r.input_power))
     kat["galileo_e1_real_capture"] = dict(file="kat_gsoc_cttc_capture_4msps_4ms.dat", fs=fs, doppler_max=10000, doppler_step=125, sampled_ms=4,
-        reference_analysis={"11": dict(delay_samples=13873, abs_doppler_hz=9500), "12": dict(delay_samples=10583, abs_doppler_hz=7250),
-            "source": "src/tests/signal_samples/GSoC_CTTC_capture_2012_07_26_4Msps_4ms_analysis.txt (plot_acq_grid_gsoc.m results)"},
+        # the figures the reference ships beside the capture (output of src/utils/matlab/plot_acq_grid_gsoc.m on its acquisition dump)
+        reference_analysis={"11": dict(delay_samples=13873, abs_doppler_hz=9500, maximum_correlation_peak=23.0285, noise_floor=1.8919, gain_db=10.8538),
+            "12": dict(delay_samples=10583, abs_doppler_hz=7250, maximum_correlation_peak=16.5534, noise_floor=1.9020, gain_db=9.3968),
+            "source": "src/tests/signal_samples/GSoC_CTTC_capture_2012_07_26_4Msps_4ms_analysis.txt (plot_acq_grid_gsoc.m results)",
+            "replica": "E1C (the script's title: 'Local replica: E1C cboc'; the sinBOC(1,1) form of the replica reproduces the listed figures, see tests/helpers.py::gsoc_grid_statistics)",
+            "script": "src/utils/matlab/plot_acq_grid_gsoc.m"},
         absent_prns=[19, 20], oracle_by_prn=real)
     json.dump(kat, open(os.path.join(HERE, "kat_expected.json"), "w"), indent=1)
 

@@ -55,3 +55,18 @@ def rel_err(got, ref, prompt_index):
     got = np.asarray(got)
     ref = np.asarray(ref)
     return float(np.max(np.abs(got - ref)) / np.abs(ref[prompt_index]))
+
+
+def gsoc_grid_statistics(grid_mag2, fs, doppler_step):
+    """The figures the reference's plot_acq_grid_gsoc.m prints for an acquisition grid (src/utils/matlab/plot_acq_grid_gsoc.m:
+    acq_grid = abs(complex correlation output); peak; noise floor = mean of the grid outside +-floor(3 fs / 1.023e6) samples and
+    +-floor(500 / step) bins around the peak; gain = 10 log10(peak / floor)).  grid_mag2: [bins][N] of |.|^2 as the engine and the
+    block hold it.  Returns (peak magnitude, noise floor, gain in dB, row, column)."""
+    g = np.sqrt(np.asarray(grid_mag2, np.float64))
+    row, col = np.unravel_index(int(np.argmax(g)), g.shape)
+    ds, dp = int(np.floor(3 * fs / 1.023e6)), int(np.floor(500 / doppler_step))
+    ng = g.copy()
+    ng[max(row - dp, 0):row + dp + 1, max(col - ds, 0):col + ds + 1] = 0.0
+    n = ng.size - (2 * ds + 1) * (2 * dp + 1)
+    floor_ = ng.sum() / n
+    return float(g[row, col]), float(floor_), float(10 * np.log10(g[row, col] / floor_)), int(row), int(col)

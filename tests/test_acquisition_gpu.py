@@ -418,3 +418,26 @@ def test_uneven_satellite_batches(gctx, oracle, monkeypatch):
         assert np.max(np.abs(acq.grid(s) - ref)) <= TOL * ref.max()
     assert min(r.test_statistics for r in res[:4]) > max(r.test_statistics for r in res[4:])
     acq.close()
+
+
+def test_gpu_grid_against_the_reference_matlab_analysis(gctx, oracle):
+    """The same reference-held figures (plot_acq_grid_gsoc.m on the GSoC 2012 capture: PRN 11 10.8538 dB, PRN 12 9.3968 dB of peak
+    over noise floor; tests/test_oracle_golden.py has the details) from the GPU's own grid, with the engine's own E1C replica."""
+    import gnsscorr
+    from helpers import gsoc_grid_statistics
+    k, x = _kat("galileo_e1_real_capture")
+    fs = k["fs"]
+    c = dict(fs_in=fs, sampled_ms=4, ms_per_code=4, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=16000.0,
+        samples_per_chip=4, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+    acq = gnsscorr.PcpsAcquisition(gctx, 2, **c)
+    for s_, prn in enumerate((11, 12)):
+        acq.set_local_code(s_, gnsscorr.galileo_e1_code_gen_complex_sampled("1C", False, prn, fs))
+    acq.dwell(x)
+    for s_, prn in enumerate((11, 12)):
+        a = k["reference_analysis"][str(prn)]
+        peak, floor_, gain, row, col = gsoc_grid_statistics(acq.grid(s_), fs, k["doppler_step"])
+        assert col == a["delay_samples"] and abs(-k["doppler_max"] + k["doppler_step"] * row) == a["abs_doppler_hz"]
+        assert abs(gain - a["gain_db"]) < 0.02, (prn, gain)
+        n2 = float(acq.fft_size) ** 2
+        assert abs(peak / n2 / a["maximum_correlation_peak"] - 1.0) < 3e-3 and abs(floor_ / n2 / a["noise_floor"] - 1.0) < 3e-3, (prn, peak / n2, floor_ / n2)
+    acq.close()

@@ -16,9 +16,10 @@
  *     E1 file -> 2920 samples / -632 Hz) and by two real captures the reference
  *     ships: the NT1065 GLONASS L1 file of its tracking tests (the search lands
  *     on the hand-over they hard-code, 1343 samples / -2750 Hz) and the GSoC 2012
- *     Galileo E1 file with its MATLAB analysis (PRN 11 / 12 delays exact); exact
- *     grid values (FFTW rounding) are not reproducible and are PARITY UNPINNED
- *     beyond those tests.
+ *     Galileo E1 file with its MATLAB analysis (PRN 11 / 12 delays exact; the
+ *     listed peak magnitudes, noise floors and their ratios reproduced to ~2e-3,
+ *     tests/test_oracle_golden.py); exact grid values (FFTW rounding) are not
+ *     reproducible and are PARITY UNPINNED beyond those tests.
  *   - rotator + dot-product accumulate (E/P/L values): PARITY UNPINNED -- the
  *     reference kernel header needs the Mako-generated <volk_gnsssdr/volk_gnsssdr.h>
  *     which cannot be generated here, and no reference test stores E/P/L values.

@@ -449,6 +449,13 @@ class Context:
     def synchronize(self):
         _check(load_library().gc_ctx_synchronize(self._h))
 
+    def register_host_buffer(self, array):
+        """gc_ctx_register_host_buffer on a numpy array (the caller keeps it alive until unregister_host_buffer)."""
+        _check(load_library().gc_ctx_register_host_buffer(self._h, _vp(array.ctypes.data), array.nbytes))
+
+    def unregister_host_buffer(self, array):
+        _check(load_library().gc_ctx_unregister_host_buffer(self._h, _vp(array.ctypes.data)))
+
     def correlator_batch_stats(self):
         """(launches, calls served, calls that shared their window's upload, largest batch) of the level-1 epoch batcher."""
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()

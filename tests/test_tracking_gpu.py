@@ -102,3 +102,60 @@ def test_sliced_epochs_equal_unsliced(gctx, oracle):
     ref = oracle.multicorrelator(sig[3:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], p["code_step"], n)
     for o in outs:
         assert rel_err(o, ref, 1) <= TOL
+
+
+def test_level1_calls_from_many_threads_are_batched_and_exact(gctx, oracle):
+    """The drop-in object driven the way the flowgraph drives it: one correlator per thread, every thread reading its own position
+    of ONE stream buffer, all calling at once (ctypes releases the GIL).  Every result must equal the same call made alone (the
+    slice count depends on the window length only, so a batch changes nothing), the calls must have been combined into fewer
+    launches, and the same holds with the buffer registered (no staging copies)."""
+    import threading
+    import gnsscorr
+    fs, n, n_thr, n_calls = 25_000_000, 25000, 12, 6
+    code = oracle.gps_l1_ca_code(4).astype(np.float32)
+    sig, truth = synth_stream([code], fs, 4 * n, seed=99, cn0_db_hz=(45.0, 45.0))
+    shifts = [np.array([-0.5, 0.0, 0.5], np.float32) for _ in range(n_thr)]
+    outs = [np.zeros(3, np.complex64) for _ in range(n_thr)]
+    offs = [(977 * t) % (2 * n) for t in range(n_thr)]
+    mcs = []
+    for t in range(n_thr):
+        mc = gnsscorr.HipMulticorrelatorRealCodes(gctx)
+        mc.set_high_dynamics_resampler(False)
+        mc.init(2 * n, 3)
+        mc.set_local_code_and_taps(1023, code, shifts[t])
+        mc.set_input_output_vectors(outs[t], sig[offs[t]:])
+        mcs.append(mc)
+    args = [(float(np.float32(0.1 * t)), float(np.float32(2e-3)), 0.0, float(np.float32(-3.25 * t)), float(np.float32(1023.0 / n)), 0.0, n) for t in range(n_thr)]
+    alone = []
+    for t in range(n_thr):
+        mcs[t].Carrier_wipeoff_multicorrelator_resampler(*args[t])
+        alone.append(outs[t].copy())
+        ref = oracle.multicorrelator(sig[offs[t]:], code, shifts[t], np.float32(args[t][0]), np.float32(args[t][1]), np.float32(args[t][3]), np.float32(args[t][4]), n)
+        assert float(np.max(np.abs(alone[t] - ref))) <= 6e-5 * np.sqrt(n) + 1e-4 * float(np.max(np.abs(ref)))
+    for registered in (False, True):
+        if registered:
+            gctx.register_host_buffer(sig)
+        b0, r0, s0, _ = gctx.correlator_batch_stats()
+        bad = []
+        barrier = threading.Barrier(n_thr)
+
+        def work(t):
+            barrier.wait()
+            for _ in range(n_calls):
+                outs[t][:] = 0
+                mcs[t].Carrier_wipeoff_multicorrelator_resampler(*args[t])
+                if not np.array_equal(outs[t], alone[t]):
+                    bad.append((t, outs[t].copy()))
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        b1, r1, s1, _ = gctx.correlator_batch_stats()
+        assert not bad, bad[:2]
+        assert r1 - r0 == n_thr * n_calls and b1 - b0 < r1 - r0  # fewer launches than calls
+        if registered:
+            gctx.unregister_host_buffer(sig)
+    for mc in mcs:
+        mc.close()

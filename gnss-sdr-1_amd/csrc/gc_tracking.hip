@@ -976,7 +976,10 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, co
                     break;
                 }
         }
-    rq->own_dev = own_pinned_dev;
+    // the staged copy keeps the 16-byte phase of the caller's pointer, like the shared and the registered paths do: the kernel's
+    // pair alignment, and with it the order of its sums, is then the same however the window reaches the GPU
+    const size_t own_lead = (uintptr_t)rq->host_sig & 15;
+    rq->own_dev = static_cast<const char*>(own_pinned_dev) + own_lead;
     if (rq->region < 0 && rq->sig_bytes > 0)
         {
             // an earlier, still queued call of the same kernel shape whose window overlaps this one: copy nothing, the leader of
@@ -998,7 +1001,7 @@ static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, co
             if (need_copy)
                 {
                     lk.unlock();
-                    if (rq->sig_bytes > 0) std::memcpy(own_pinned, rq->host_sig, rq->sig_bytes);
+                    if (rq->sig_bytes > 0) std::memcpy(static_cast<char*>(own_pinned) + own_lead, rq->host_sig, rq->sig_bytes);
                     lk.lock();
                     rq->self_copied = true;
                     rq->copy_done = true;

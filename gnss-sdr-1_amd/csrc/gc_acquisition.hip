@@ -52,7 +52,34 @@ struct gc_acq
     std::vector<char> code_set;
     int64_t freq_offset_hz = 0;  // d_old_freq: intermediate frequency / GLONASS FDMA channel offset
     bool grid_logically_zero = true;  // gc_acq_reset() since the last dwell: the grid reads as zeros
+    // The statistics of a dwell (acq_final_kernel) are computed when somebody can see them -- a fetch -- or when the next dwell
+    // would not reproduce their side effect, not after every dwell: the reference evaluates the statistic after each dwell
+    // (pcps_acquisition.cc:747-755), but a caller that enqueues the dwells of a search back to back and fetches once only ever
+    // reads the last one.  The one side effect, the scratch image of d_tmp_buffer, is overwritten completely by the column pass
+    // of an ACCUMULATING dwell (last-bin magnitudes, :737), so a pending evaluation may be dropped in front of such a dwell and must
+    // run in front of any other.
+    bool final_pending = false;
+    AcqFinalArgs final_args{};
+    hipStream_t final_stream = nullptr;
 };
+
+// runs the pending statistics kernel, if any, on `st`
+static hipError_t acq_flush_final(gc_acq* a, hipStream_t st)
+{
+    if (!a->final_pending) return hipSuccess;
+    a->final_pending = false;
+    // the dwell it belongs to was enqueued on final_stream: same stream in every sensible use; otherwise order the two
+    if (a->final_stream != st)
+        {
+            hipEvent_t ev;
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev, a->final_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+            if (e == hipSuccess) (void)hipEventDestroy(ev);
+            if (e != hipSuccess) return e;
+        }
+    return acq_launch_final(st, a->final_args, a->n_sats);
+}
 
 static void acq_release(gc_acq* a)
 {
@@ -77,6 +104,17 @@ static void acq_release(gc_acq* a)
     if (a->h_results) (void)hipHostFree(a->h_results);
 }
 
+// The wipe-off tables are kept in the row-permuted layout the forward row pass reads (P[bin][a][b] = wipe[bin][a + N1 * b]): the
+// product x * wipeoff[bin] (pcps_acquisition.cc:717) is then the two-operand load of that pass -- A = the table, B = the permuted
+// input block, shared by every bin -- instead of a kernel of its own that writes and re-reads n_bins x N products per dwell.
+static hipError_t acq_permute_wipe_table(gc_acq* a, float2* table, int n_bins, hipStream_t st)
+{
+    const size_t N = a->fft_size;
+    hipError_t e = acq_launch_permute(st, table, nullptr, a->d_xw, a->plan, (int)N, n_bins, N, 0, N);
+    if (e == hipSuccess) e = hipMemcpyAsync(table, a->d_xw, (size_t)n_bins * N * sizeof(float2), hipMemcpyDeviceToDevice, st);
+    return e;
+}
+
 // d_grid_doppler_wipeoffs of the coarse grid: exp(-j*2*pi*(d_old_freq + doppler)/fs * n) with the reference's float32
 // running phase (update_grid_doppler_wipeoffs :371-380, update_local_carrier :296-310); d_old_freq = freq_offset_hz
 static hipError_t acq_build_main_wipeoffs(gc_acq* a, hipStream_t st)
@@ -94,6 +132,7 @@ static hipError_t acq_build_main_wipeoffs(gc_acq* a, hipStream_t st)
     if (e != hipSuccess) return e;
     e = hipMemcpy(d_inc, inc.data(), sizeof(float) * a->n_bins_main, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe_main, (int)a->n_bins_main, (int)a->fft_size);
+    if (e == hipSuccess) e = acq_permute_wipe_table(a, a->d_wipe_main, (int)a->n_bins_main, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_inc);
     return e;
@@ -336,6 +375,7 @@ gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz)
     GC_HIP(hipMalloc(&d_inc, sizeof(float) * n2));
     hipError_t e = hipMemcpy(d_inc, inc.data(), sizeof(float) * n2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe2, (int)n2, (int)a->fft_size);
+    if (e == hipSuccess) e = acq_permute_wipe_table(a, a->d_wipe2, (int)n2, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_inc);
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_step_two: %s", hipGetErrorString(e));
@@ -365,12 +405,22 @@ static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hi
     a->dwell_counter++;
     hipError_t e = hipSuccess;
     const bool bt = a->conf.bit_transition_flag != 0;
+    if (a->final_pending)
+        {
+            // an accumulating dwell on the same grid overwrites the scratch the pending evaluation would have left: drop it
+            const bool reproduces = a->dwell_counter > 1 && !a->use_cfar && !bt && a->final_args.n_bins == n_bins && a->final_stream == st;
+            if (reproduces)
+                a->final_pending = false;
+            else
+                e = acq_flush_final(a, st);
+        }
     if (a->use_cfar || bt)
         e = acq_launch_input_power(st, dev_iq, (int)a->consumed, (int)N, a->d_power, a->d_tmp, a->n_sats, N);
-    // x * wipeoff[d] for every bin (:717), zero padded to fft_size (:680-688), row-permuted
-    if (e == hipSuccess) e = acq_launch_permute(st, dev_iq, a->d_wipe, a->d_xw, a->plan, (int)a->consumed, n_bins, 0, N, N);
-    // forward FFT per bin (:721), shared by every satellite
-    if (e == hipSuccess) e = acq_launch_rows(st, false, a->plan, n_bins, a->d_xw, AcqCellMap{1, n_bins}, nullptr, AcqCellMap{1, 1}, a->d_Q, a->d_wN2, a->d_wN);
+    // the input block, zero padded to fft_size (:680-688), row-permuted once
+    if (e == hipSuccess) e = acq_launch_permute(st, dev_iq, nullptr, a->d_xw, a->plan, (int)a->consumed, 1, 0, 0, 0);
+    // x * wipeoff[d] (:717) fused into the load of the forward FFT per bin (:721), which every satellite shares
+    if (e == hipSuccess)
+        e = acq_launch_rows(st, false, a->plan, n_bins, a->d_wipe, AcqCellMap{1, n_bins}, a->d_xw, AcqCellMap{n_bins, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
     if (e == hipSuccess) e = acq_launch_cols(st, false, ACQ_EPI_PERM, a->plan, n_bins, a->d_Q, a->d_X, nullptr);
     // per satellite and bin: * conj(FFT(code)) (:724), IFFT (:727), |.|^2 (+=) (:730-739)
     for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += a->sats_per_batch)
@@ -415,7 +465,9 @@ static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hi
             f.center_step_two = a->center_step_two;
             f.doppler_step2 = a->conf.doppler_step2;
             f.n_bins_step2 = (int)a->conf.num_doppler_bins_step2;
-            e = acq_launch_final(st, f, a->n_sats);
+            a->final_args = f;
+            a->final_stream = st;
+            a->final_pending = true;
         }
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: kernel launch failed: %s", hipGetErrorString(e));
     a->grid_logically_zero = false;
@@ -441,6 +493,7 @@ gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream)
 // results of the last dwell to the host; the caller holds the context mutex
 static gc_status acq_fetch(gc_acq* a, gc_acq_result* host_results, hipStream_t st)
 {
+    GC_HIP(acq_flush_final(a, st));
     GC_HIP(hipMemcpyAsync(a->h_results, a->d_results, sizeof(gc_acq_result) * a->n_sats, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
     std::memcpy(host_results, a->h_results, sizeof(gc_acq_result) * a->n_sats);

@@ -612,12 +612,12 @@ static void test_level1_scales_with_channel_threads()
             EXPECT(bad.load() == 0, "%d calls failed", bad.load());
             EXPECT(r1 - r0 == static_cast<uint64_t>(n_threads) * calls, "batcher served %llu calls", static_cast<unsigned long long>(r1 - r0));
             // The calls overlap: 64 threads finish in less than 64 x the single-thread latency / 8 on the flowgraph's topology, with
-            // or without the buffer registered (measured 9.1-10.3x and 10.4-11.8x); 8.4-9.8x when every thread hands in the same
-            // pointer (gate 6.5: the first arrival stages the window before anything can be launched); with a buffer per thread
-            // every call stages and moves its own 200 KB (4.0-4.5x).  Every thread sleeps and is woken once per call, 64 threads on
+            // or without the buffer registered (measured 8.8-10.3x and 9.9-11.8x; the gate of the unregistered form leaves a margin for
+            // a busy host); 8.3-9.8x when every thread hands in the same pointer; with a buffer per thread every call stages and moves
+            // its own 200 KB (4.6-4.8x).  Every thread sleeps and is woken once per call, 64 threads on
             // the box's 16 cores: the gates leave room for the scheduler's mood.
             const bool timing_gates = std::getenv("GNSSCORR_SELFTEST_NO_TIMING") == nullptr;  // sanitizer builds check values only
-            static const double gate[4] = {6.5, 8.0, 8.0, 3.0};
+            static const double gate[4] = {6.0, 7.0, 8.0, 3.0};  // measured 8.3-9.8, 8.8-10.3, 9.9-11.8, 4.6-4.8
             EXPECT(!timing_gates || total_us < serial_us / gate[topo], "no overlap: %.0f us for %d x %d calls, %.1f us each alone", total_us, n_threads, calls, single_us);
             for (int t = 0; t < n_threads; t += 7)
                 {

@@ -28,7 +28,11 @@ enum
     ACQ_EPI_COMPLEX = 0,  // store the transform (natural order)
     ACQ_EPI_COMPLEX_CONJ_PERM = 1,  // store conj(transform) in row-permuted order (code FFT)
     ACQ_EPI_PERM = 2,     // store the transform in row-permuted order (signal FFT)
-    ACQ_EPI_MAG = 3       // |.|^2 into the search grid (+ per-block row maxima)
+    ACQ_EPI_MAG = 3,      // |.|^2 stored into the search grid (+ per-block row maxima): first dwell
+    ACQ_EPI_MAG2 = 4,     // two dwells at once: Q holds [sat][2 * n_bins][N], the second n_bins being the next dwell; the grid gets
+                          // |.|^2 of the first + |.|^2 of the second, written once
+    ACQ_EPI_MAG2_ACC = 5, // the same on top of earlier dwells: (grid + first) + second
+    ACQ_EPI_MAG_ACC = 6   // grid += |.|^2: later dwells
 };
 
 struct AcqMagArgs
@@ -37,7 +41,6 @@ struct AcqMagArgs
     float* tmp;           // per-satellite d_tmp_buffer image [sat][fft_size] (may be null)
     float* blk_max_val;   // [cell][n_blocks]
     unsigned* blk_max_idx;
-    int accumulate;       // 0: first dwell (store), 1: add to the grid
     int offset;           // first kept output sample (bit_transition: fft_size/2)
     int eff;              // kept samples per row
     int n_bins;           // cells per satellite

@@ -373,7 +373,7 @@ struct AcqRows2Args
     int n_bins;  // cells per satellite (= mapA.mod)
     int n_sats;  // satellites in this launch; cell = sat * n_bins + bin
     int n_groups;  // workgroups that have rows
-    int sat_fastest;  // pair kernel: row order (bin, k1, sat) instead of (bin, sat, k1)
+    int sat_fastest;  // pair kernels: row order, 0 = (bin, sat, k1), 1 = (bin, k1, sat), 2 = (k1, bin, sat; planar kernel only)
     int dbg;          // $GNSSCORR_ACQ_DBG, timing experiments on acq_rows3_kernel only (results are WRONG with any bit set):
                       // 1 = no global input loads, 2 = no global stores, 4 = no twiddle loads, 8 = no butterflies
 };
@@ -841,7 +841,14 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
     {
         const float inv_n1 = 1.0f / (float)N1, inv_ns = 1.0f / (float)g.n_sats;
         const int rowid = row0 + row;
-        if (g.sat_fastest)
+        if (g.sat_fastest == 2)
+            {
+                const int kb = fdiv(rowid, inv_ns);
+                sat = rowid - kb * g.n_sats;
+                k1 = fdiv(kb, 1.0f / (float)g.n_bins);
+                bin = kb - k1 * g.n_bins;
+            }
+        else if (g.sat_fastest)
             {
                 const int bk = fdiv(rowid, inv_ns);
                 sat = rowid - bk * g.n_sats;
@@ -1144,8 +1151,11 @@ static __device__ __forceinline__ MaxPair max_pair(MaxPair a, MaxPair b)
 #define ACQ_COLS_WAVES 1  // minimum waves per SIMD the columns kernel is compiled for.  4 (128 registers, a fourth workgroup per CU) was
                           // measured: the 25-point column transform then spills 43 registers and a search takes 0.60 instead of 0.50 ms
 #endif
+#ifndef ACQ_COLS_PAIR_WAVES
+#define ACQ_COLS_PAIR_WAVES 3  // the two-dwell epilogue is held to the registers of the one-dwell kernel (168: three waves per SIMD)
+#endif
 template <int N1, bool INV, int EPI>
-__global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ACQ_COLS_WAVES : 1)) void acq_cols_kernel(AcqFftPlan plan, const float2* __restrict__ Q,
+__global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || EPI == ACQ_EPI_MAG2_ACC) ? ACQ_COLS_PAIR_WAVES : ACQ_COLS_WAVES) : 1)) void acq_cols_kernel(AcqFftPlan plan, const float2* __restrict__ Q,
     float2* __restrict__ out, AcqMagArgs mag)
 {
     const int N2 = plan.N2, N = plan.N;
@@ -1153,11 +1163,27 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ACQ_COLS_WAVES : 1)) void 
     const int cell = blockIdx.y;
     const bool active = n2 < N2;
     float2 v0[N1], v1[N1];
-    const float2* q = Q + (size_t)cell * N;
+    // ACQ_EPI_MAG2: the rows pass ran over 2 * n_bins "bins" per satellite, the second half being the next dwell's spectra
+    constexpr bool PAIR = (EPI == ACQ_EPI_MAG2 || EPI == ACQ_EPI_MAG2_ACC);
+    const size_t qcell = PAIR ? (size_t)(cell / mag.n_bins) * (2 * mag.n_bins) + cell % mag.n_bins : (size_t)cell;
+    const float2* q = Q + qcell * N;
 #pragma unroll
     for (int k = 0; k < N1; k++) v0[k] = active ? q[(size_t)k * N2 + n2] : make_float2(0.f, 0.f);
     RegFft<N1, 1, N1, INV>::run(v0, v1, plan.w1);
     float2* res = RegFft<N1, 1, N1, INV>::result_in_first ? v0 : v1;
+    // first dwell's magnitudes wait in LDS (N1 x 256 floats: 25 KB of the 160) while the second column is transformed: in
+    // registers they cost the third wave per SIMD (208 instead of 168), and so do the second column's loads hoisted above the first transform
+    __shared__ float p1[PAIR ? N1 : 1][PAIR ? ACQ_THREADS : 1];
+    if (PAIR)
+        {
+#pragma unroll
+            for (int k = 0; k < N1; k++) p1[PAIR ? k : 0][PAIR ? threadIdx.x : 0] = res[k].x * res[k].x + res[k].y * res[k].y;
+            __builtin_amdgcn_sched_barrier(0);
+            const float2* q2 = q + (size_t)mag.n_bins * N;
+#pragma unroll
+            for (int k = 0; k < N1; k++) v0[k] = active ? q2[(size_t)k * N2 + n2] : make_float2(0.f, 0.f);
+            RegFft<N1, 1, N1, INV>::run(v0, v1, plan.w1);
+        }
 
     if (EPI == ACQ_EPI_COMPLEX)
         {
@@ -1189,19 +1215,22 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ACQ_COLS_WAVES : 1)) void 
             // |.|^2, non-coherent accumulation, per-block maximum of the grid row
             float* g = mag.grid + (size_t)cell * N;
             const int sat = cell / mag.n_bins, bin = cell % mag.n_bins;
-            float* tmp = (mag.tmp && mag.accumulate && bin == mag.tmp_bin) ? mag.tmp + (size_t)sat * N : nullptr;
+            // the scratch image holds the LAST dwell's own magnitudes of one bin whenever that dwell accumulated (the second of a fused pair always does)
+            float* tmp = (mag.tmp && (EPI == ACQ_EPI_MAG_ACC || PAIR) && bin == mag.tmp_bin) ? mag.tmp + (size_t)sat * N : nullptr;
             MaxPair best = {-1.0f, 0xffffffffu};
             if (active)
                 {
                     // non-coherent accumulation: all previous grid values are fetched before the first store (the compiler
                     // cannot prove that g[idx(k)] and g[idx(k')] differ, so a load after a store would wait for it: N1 serial
                     // round trips made the accumulating launches 2.5x slower than the first dwell's)
-                    float prev[N1];
+                    constexpr bool HAS_PREV = (EPI == ACQ_EPI_MAG_ACC || EPI == ACQ_EPI_MAG2_ACC);  // whether the grid holds earlier dwells is part of the instantiation:
+                    // the previous values are fetched up front (25 registers, the third instead of the fourth wave per SIMD) only where they exist
+                    float prev[HAS_PREV ? N1 : 1];
 #pragma unroll
-                    for (int k = 0; k < N1; k++)
+                    for (int k = 0; k < (HAS_PREV ? N1 : 0); k++)
                         {
                             const int idx = n2 + N2 * k - mag.offset;
-                            prev[k] = (mag.accumulate && idx >= 0 && idx < mag.eff) ? g[idx] : 0.0f;
+                            prev[k] = (idx >= 0 && idx < mag.eff) ? g[idx] : 0.0f;
                         }
 #pragma unroll
                     for (int k = 0; k < N1; k++)
@@ -1212,10 +1241,17 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ACQ_COLS_WAVES : 1)) void 
                                 {
                                     float p = res[k].x * res[k].x + res[k].y * res[k].y;
                                     float val = p;
-                                    if (mag.accumulate)
+                                    if (PAIR)
+                                        {
+                                            // dwell 1: grid (+)= p1; dwell 2: grid += p, in the order two separate passes add
+                                            const float first = p1[PAIR ? k : 0][PAIR ? threadIdx.x : 0];
+                                            val = (EPI == ACQ_EPI_MAG2_ACC ? prev[HAS_PREV ? k : 0] + first : first) + p;
+                                            if (tmp) tmp[idx] = p;
+                                        }
+                                    else if (EPI == ACQ_EPI_MAG_ACC)
                                         {
                                             if (tmp) tmp[idx] = p;
-                                            val = prev[k] + p;
+                                            val = prev[HAS_PREV ? k : 0] + p;
                                         }
                                     g[idx] = val;
                                     MaxPair c = {val, (unsigned)idx};
@@ -1780,6 +1816,28 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             }();
             if (interleaved_pairs && entry->pair_fwd)
                 fn = inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<true, 10, 10, 10>) : reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<false, 10, 10, 10>);
+            // row order of the pair kernel: 0 = (bin, sat, k1), 1 = (bin, k1, sat), 2 = (k1, bin, sat) with the last digit running fastest.
+            // An XCD walks a contiguous eighth of the rows; with 2 it needs row k1 of every spectrum and of every code at a time (a few
+            // hundred KB, read once per launch), with 0 / 1 it sweeps all the codes once per bin and its L2 (4 MB) has dropped them by then.
+            static const int row_order = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");
+                return e ? std::atoi(e) : 2;
+            }();
+            g.sat_fastest = (B != nullptr && g.n_sats > 1) ? row_order : 0;
+            static const int dbg = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_DBG");  // phase-elimination timing (ACQ_ROWS3_DBG builds only)
+                return e ? std::atoi(e) : 0;
+            }();
+            g.dbg = dbg;
+            static const int persist = [] {
+                const char* e = std::getenv("GNSSCORR_ACQ_PERSIST");  // workgroups per CU of the persistent row launch (0: one block per group)
+                return e ? std::atoi(e) : 4;  // measured: 4 per CU (what the LDS admits) is 2 % faster than a block per group
+            }();
+            if (persist > 0 && entry->pair_fwd && fn == (inverse ? entry->pair_inv : entry->pair_fwd))
+                {
+                    const unsigned cap = (unsigned)(persist * 256);
+                    if (grid2.x > cap) grid2.x = cap;
+                }
             return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);
         }
     dim3 grid(plan.N1, n_cells);
@@ -1820,6 +1878,9 @@ static hipError_t launch_cols_n1(hipStream_t st, bool inverse, int epilogue, con
                 {
                 case ACQ_EPI_COMPLEX: LAUNCH(true, ACQ_EPI_COMPLEX); break;
                 case ACQ_EPI_MAG: LAUNCH(true, ACQ_EPI_MAG); break;
+                case ACQ_EPI_MAG_ACC: LAUNCH(true, ACQ_EPI_MAG_ACC); break;
+                case ACQ_EPI_MAG2: LAUNCH(true, ACQ_EPI_MAG2); break;
+                case ACQ_EPI_MAG2_ACC: LAUNCH(true, ACQ_EPI_MAG2_ACC); break;
                 default: return hipErrorInvalidValue;
                 }
         }

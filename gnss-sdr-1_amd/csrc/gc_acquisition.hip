@@ -61,7 +61,20 @@ struct gc_acq
     bool final_pending = false;
     AcqFinalArgs final_args{};
     hipStream_t final_stream = nullptr;
+    // The inverse passes of a dwell that more dwells are expected to follow (dwell counter < max_dwells, plain statistic) are held
+    // back, its spectra parked in slot 0 of d_X: if the next call is an accumulating dwell on the same stream, BOTH dwells go through
+    // one row pass over 2 * n_bins spectra per satellite and one column pass that adds the two |.|^2 and writes the grid once
+    // (ACQ_EPI_MAG2) -- the grid read-modify-write of the second dwell and the first dwell's grid write never happen.  Anything
+    // else (a fetch, a grid read, a change of codes or of the Doppler grid) first runs the held-back passes alone, so every caller
+    // sees what per-dwell processing would have produced; gc_acq_reset() drops them with the grid.
+    bool inv_pending = false;
+    bool inv_accumulate = false;
+    int inv_n_bins = 0;
+    hipStream_t inv_stream = nullptr;
+    bool fuse_dwells = true;  // $GNSSCORR_ACQ_FUSE=0: every dwell on its own
 };
+
+static hipError_t acq_flush_inverse(gc_acq* a, hipStream_t st);
 
 // runs the pending statistics kernel, if any, on `st`
 static hipError_t acq_flush_final(gc_acq* a, hipStream_t st)
@@ -222,7 +235,8 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
         ACQ_TRY(hipMalloc(&a->d_wipe2, (size_t)conf->num_doppler_bins_step2 * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_codes, (size_t)n_sats * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_xw, (size_t)a->n_bins_alloc * N * sizeof(float2)));
-    ACQ_TRY(hipMalloc(&a->d_X, (size_t)a->n_bins_alloc * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_X, (size_t)2 * a->n_bins_alloc * N * sizeof(float2)));  // two dwells' spectra (see inv_pending)
+    if (const char* e = std::getenv("GNSSCORR_ACQ_FUSE")) a->fuse_dwells = std::atoi(e) != 0;
     ACQ_TRY(hipMalloc(&a->d_Q, q_cells * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_grid, (size_t)n_sats * a->n_bins_alloc * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_tmp, (size_t)n_sats * N * sizeof(float)));
@@ -297,6 +311,7 @@ gc_status gc_acq_set_local_code(gc_acq* a, int sat, const float* code)
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
     hipStream_t st = a->ctx->stream;
     const size_t N = a->fft_size;
+    GC_HIP(acq_flush_inverse(a, st));  // a held-back dwell was searched with the codes of its time (and d_Q is the staging buffer below)
     // [0 .. 0 c_0 .. c_L] layouts of set_local_code (:252-269)
     std::vector<float2> buf(N, make_float2(0.f, 0.f));
     const float2* c = reinterpret_cast<const float2*>(code);
@@ -326,6 +341,7 @@ gc_status gc_acq_set_frequency_offset(gc_acq* a, int64_t offset_hz)
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
     if (offset_hz == a->freq_offset_hz) return GC_OK;
+    GC_HIP(acq_flush_inverse(a, a->ctx->stream));  // a held-back dwell was wiped off with the tables of its time
     GC_HIP(hipStreamSynchronize(a->ctx->stream));
     a->freq_offset_hz = offset_hz;
     hipError_t e = acq_build_main_wipeoffs(a, a->ctx->stream);
@@ -343,6 +359,7 @@ gc_status gc_acq_reset(gc_acq* a)
     // search at cfg4 sizes, and it would have to be ordered against dwells enqueued on caller streams.
     a->dwell_counter = 0;
     a->grid_logically_zero = true;
+    a->inv_pending = false;  // a held-back dwell goes with the grid it would have been added to
     return GC_OK;
 }
 
@@ -352,6 +369,7 @@ gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz)
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
     hipStream_t st = a->ctx->stream;
+    GC_HIP(acq_flush_inverse(a, st));  // a held-back dwell belongs to the grid that is active now
     if (!enable)
         {
             a->step_two = false;
@@ -387,60 +405,37 @@ gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz)
     return GC_OK;
 }
 
-// one dwell of every satellite slot on `st`; the caller holds the context mutex
-static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hipStream_t st)
+// per satellite and bin: * conj(FFT(code)) (pcps_acquisition.cc:724), IFFT (:727), |.|^2 (+=) (:730-739) of the spectra in d_X, in
+// batches of satellites; `pair`: d_X holds two dwells (slot 0, then slot 1 at n_bins spectra), summed into the grid in one pass
+static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumulate)
 {
-    for (int s = 0; s < a->n_sats; s++)
-        if (!a->code_set[s]) return gc_fail(GC_ERR_STATE, "gc_acq_dwell: satellite slot %d has no local code", s);
-    const float2* dev_iq = static_cast<const float2*>(dev_iq_in);
-    if (iq_format != GC_IQ_F32)
-        {
-            // d_cshort path of acquisition_core (:676-679): convert the block, then the float search
-            hipError_t ec = acq_launch_convert(st, iq_format, dev_iq_in, a->d_cvt, (int)a->consumed);
-            if (ec != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: input conversion failed: %s", hipGetErrorString(ec));
-            dev_iq = a->d_cvt;
-        }
     const size_t N = a->fft_size;
     const int n_bins = (int)a->n_bins;
-    a->dwell_counter++;
-    hipError_t e = hipSuccess;
     const bool bt = a->conf.bit_transition_flag != 0;
-    if (a->final_pending)
+    const int spectra = pair ? 2 * n_bins : n_bins;  // per satellite
+    const int q_cells = a->sats_per_batch * (int)a->n_bins_alloc;
+    int per_batch = q_cells / spectra;
+    {
+        const int n_batches = (a->n_sats + per_batch - 1) / per_batch;
+        per_batch = (a->n_sats + n_batches - 1) / n_batches;  // equal batches
+    }
+    hipError_t e = hipSuccess;
+    for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += per_batch)
         {
-            // an accumulating dwell on the same grid overwrites the scratch the pending evaluation would have left: drop it
-            const bool reproduces = a->dwell_counter > 1 && !a->use_cfar && !bt && a->final_args.n_bins == n_bins && a->final_stream == st;
-            if (reproduces)
-                a->final_pending = false;
-            else
-                e = acq_flush_final(a, st);
-        }
-    if (a->use_cfar || bt)
-        e = acq_launch_input_power(st, dev_iq, (int)a->consumed, (int)N, a->d_power, a->d_tmp, a->n_sats, N);
-    // the input block, zero padded to fft_size (:680-688), row-permuted once
-    if (e == hipSuccess) e = acq_launch_permute(st, dev_iq, nullptr, a->d_xw, a->plan, (int)a->consumed, 1, 0, 0, 0);
-    // x * wipeoff[d] (:717) fused into the load of the forward FFT per bin (:721), which every satellite shares
-    if (e == hipSuccess)
-        e = acq_launch_rows(st, false, a->plan, n_bins, a->d_wipe, AcqCellMap{1, n_bins}, a->d_xw, AcqCellMap{n_bins, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
-    if (e == hipSuccess) e = acq_launch_cols(st, false, ACQ_EPI_PERM, a->plan, n_bins, a->d_Q, a->d_X, nullptr);
-    // per satellite and bin: * conj(FFT(code)) (:724), IFFT (:727), |.|^2 (+=) (:730-739)
-    for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += a->sats_per_batch)
-        {
-            const int ns = std::min(a->sats_per_batch, a->n_sats - s0);
-            const int cells = ns * n_bins;
-            e = acq_launch_rows(st, true, a->plan, cells, a->d_X, AcqCellMap{1, n_bins}, a->d_codes + (size_t)s0 * N,
-                AcqCellMap{n_bins, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
+            const int ns = std::min(per_batch, a->n_sats - s0);
+            e = acq_launch_rows(st, true, a->plan, ns * spectra, a->d_X, AcqCellMap{1, spectra}, a->d_codes + (size_t)s0 * N,
+                AcqCellMap{spectra, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
             if (e != hipSuccess) break;
             AcqMagArgs m;
             m.grid = a->d_grid + (size_t)s0 * n_bins * N;
             m.tmp = a->d_tmp + (size_t)s0 * N;
             m.blk_max_val = a->d_blkv + (size_t)s0 * n_bins * a->n_blocks;
             m.blk_max_idx = a->d_blki + (size_t)s0 * n_bins * a->n_blocks;
-            m.accumulate = a->dwell_counter > 1 ? 1 : 0;
             m.offset = bt ? (int)a->eff : 0;
             m.eff = (int)a->eff;
             m.n_bins = n_bins;
             m.tmp_bin = n_bins - 1;
-            e = acq_launch_cols(st, true, ACQ_EPI_MAG, a->plan, cells, a->d_Q, nullptr, &m);
+            e = acq_launch_cols(st, true, pair ? (accumulate ? ACQ_EPI_MAG2_ACC : ACQ_EPI_MAG2) : (accumulate ? ACQ_EPI_MAG_ACC : ACQ_EPI_MAG), a->plan, ns * n_bins, a->d_Q, nullptr, &m);
         }
     if (e == hipSuccess)
         {
@@ -469,6 +464,104 @@ static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hi
             a->final_stream = st;
             a->final_pending = true;
         }
+    return e;
+}
+
+// makes `st` wait for what has been enqueued on `other` so far
+static hipError_t acq_order_after(hipStream_t st, hipStream_t other)
+{
+    if (st == other) return hipSuccess;
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, other);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+    if (e == hipSuccess) (void)hipEventDestroy(ev);
+    return e;
+}
+
+// runs the held-back inverse passes of the last dwell, if any, on `st` (its statistics become the pending ones)
+static hipError_t acq_flush_inverse(gc_acq* a, hipStream_t st)
+{
+    if (!a->inv_pending) return hipSuccess;
+    a->inv_pending = false;
+    hipError_t e = acq_order_after(st, a->inv_stream);
+    // statistics of an earlier dwell still pending: the dwell held back here accumulates onto that grid (or it would have flushed them)
+    if (e == hipSuccess && a->final_pending)
+        {
+            const bool reproduces = a->inv_accumulate && a->final_args.n_bins == a->inv_n_bins && a->final_stream == st;
+            if (reproduces)
+                a->final_pending = false;
+            else
+                e = acq_flush_final(a, st);
+        }
+    if (e == hipSuccess) e = acq_inverse(a, st, false, a->inv_accumulate);
+    return e;
+}
+
+// one dwell of every satellite slot on `st`; the caller holds the context mutex
+static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hipStream_t st)
+{
+    for (int s = 0; s < a->n_sats; s++)
+        if (!a->code_set[s]) return gc_fail(GC_ERR_STATE, "gc_acq_dwell: satellite slot %d has no local code", s);
+    const float2* dev_iq = static_cast<const float2*>(dev_iq_in);
+    if (iq_format != GC_IQ_F32)
+        {
+            // d_cshort path of acquisition_core (:676-679): convert the block, then the float search
+            hipError_t ec = acq_launch_convert(st, iq_format, dev_iq_in, a->d_cvt, (int)a->consumed);
+            if (ec != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: input conversion failed: %s", hipGetErrorString(ec));
+            dev_iq = a->d_cvt;
+        }
+    const size_t N = a->fft_size;
+    const int n_bins = (int)a->n_bins;
+    a->dwell_counter++;
+    hipError_t e = hipSuccess;
+    const bool bt = a->conf.bit_transition_flag != 0;
+    const bool accumulate = a->dwell_counter > 1;
+    const bool plain = !a->use_cfar && !bt;
+    // a dwell is held back: this one joins it if it adds to the same grid, otherwise the held-back passes run first
+    bool pair = false;
+    if (a->inv_pending)
+        {
+            pair = accumulate && plain && a->inv_n_bins == n_bins && a->inv_stream == st;
+            if (!pair) e = acq_flush_inverse(a, st);
+        }
+    if (e == hipSuccess && a->final_pending)
+        {
+            // an accumulating dwell on the same grid overwrites the scratch the pending evaluation would have left: drop it
+            const bool reproduces = accumulate && plain && a->final_args.n_bins == n_bins && a->final_stream == st;
+            if (reproduces)
+                a->final_pending = false;
+            else
+                e = acq_flush_final(a, st);
+        }
+    if (e == hipSuccess && (a->use_cfar || bt))
+        e = acq_launch_input_power(st, dev_iq, (int)a->consumed, (int)N, a->d_power, a->d_tmp, a->n_sats, N);
+    // the input block, zero padded to fft_size (:680-688), row-permuted once
+    if (e == hipSuccess) e = acq_launch_permute(st, dev_iq, nullptr, a->d_xw, a->plan, (int)a->consumed, 1, 0, 0, 0);
+    // x * wipeoff[d] (:717) fused into the load of the forward FFT per bin (:721), which every satellite shares
+    if (e == hipSuccess)
+        e = acq_launch_rows(st, false, a->plan, n_bins, a->d_wipe, AcqCellMap{1, n_bins}, a->d_xw, AcqCellMap{n_bins, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
+    float2* X = a->d_X + (pair ? (size_t)n_bins * N : 0);
+    if (e == hipSuccess) e = acq_launch_cols(st, false, ACQ_EPI_PERM, a->plan, n_bins, a->d_Q, X, nullptr);
+    if (e == hipSuccess)
+        {
+            const int q_cells = a->sats_per_batch * (int)a->n_bins_alloc;
+            if (pair)
+                {
+                    a->inv_pending = false;
+                    e = acq_inverse(a, st, true, a->inv_accumulate);
+                }
+            else if (a->fuse_dwells && plain && a->dwell_counter < a->max_dwells && q_cells >= 2 * n_bins)
+                {
+                    // more dwells of this search are expected: hold the inverse passes back (see gc_acq::inv_pending)
+                    a->inv_pending = true;
+                    a->inv_accumulate = accumulate;
+                    a->inv_n_bins = n_bins;
+                    a->inv_stream = st;
+                }
+            else
+                e = acq_inverse(a, st, false, accumulate);
+        }
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: kernel launch failed: %s", hipGetErrorString(e));
     a->grid_logically_zero = false;
     return GC_OK;
@@ -493,6 +586,7 @@ gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream)
 // results of the last dwell to the host; the caller holds the context mutex
 static gc_status acq_fetch(gc_acq* a, gc_acq_result* host_results, hipStream_t st)
 {
+    GC_HIP(acq_flush_inverse(a, st));
     GC_HIP(acq_flush_final(a, st));
     GC_HIP(hipMemcpyAsync(a->h_results, a->d_results, sizeof(gc_acq_result) * a->n_sats, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));
@@ -576,6 +670,7 @@ gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid)
             std::memset(host_grid, 0, n * sizeof(float));
             return GC_OK;
         }
+    GC_HIP(acq_flush_inverse(a, a->ctx->stream));
     GC_HIP(hipStreamSynchronize(a->ctx->stream));
     GC_HIP(hipMemcpy(host_grid, a->d_grid + (size_t)sat * n, n * sizeof(float), hipMemcpyDeviceToHost));
     return GC_OK;

@@ -471,12 +471,17 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 // With SC16 the returned pair holds the two 32-bit integer sums as bit patterns.
 // With DATA (pilot tracking) cd.code2 is the data component's replica: its prompt sum is returned to tid == NTAPS and the
 // window needs 2x the LDS floats.
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF>
+#include "trk_chips.hpp"
+
+// CHIPS: the plain float loop summed per chip (trk_chips.hpp); the caller provides THREADS / 64 * TRK_CHIPS_WAVE_FLOATS more
+// floats of LDS behind the code window (rounded up to 16 bytes)
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF, bool CHIPS = false>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
     int lds_table_floats, float* lds)
 {
     // lds[0..HDRF): header (wave partials); then the code window
-    constexpr int CHUNK = 2 * THREADS;
+    static_assert(!CHIPS || (!HDR && !HDC && !CC && !SC16 && FMT == GC_IQ_F32), "the chip-domain loop exists for the plain float correlator");
+    constexpr int CHUNK = CHIPS ? TRK_SEG : 2 * THREADS;  // unit of the slicing
     constexpr int HDRF = trk_hdr_floats(THREADS);
     float* table = lds + HDRF;
     const int tid = threadIdx.x;
@@ -633,7 +638,15 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
 #pragma unroll
     for (int t = 0; t < NACC; t++) accr[t] = acci[t] = 0.0f;
 
-    if (windowed)
+    if constexpr (CHIPS)
+        {
+            float* scratch = table + ((lds_table_floats + 3) & ~3);
+            if (windowed)
+                trk_loop_chips<NTAPS, true, THREADS, DATA>(base, table, table2, a, N, V, c0, c1, lo, L, step, rem, shifts, theta0, dtheta, scratch, accr, acci);
+            else
+                trk_loop_chips<NTAPS, false, THREADS, DATA>(base, table, table2, a, N, V, c0, c1, 0, L, step, rem, shifts, theta0, dtheta, scratch, accr, acci);
+        }
+    else if (windowed)
         trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
     else
         trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);

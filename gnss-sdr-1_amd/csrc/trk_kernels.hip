@@ -27,8 +27,11 @@
 #endif
 static __device__ __forceinline__ short sat16(int v) { return (short)min(max(v, -32768), 32767); }
 
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false>
-__global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_kernel(
+#ifndef TRK_CHIPS_WAVES
+#define TRK_CHIPS_WAVES 4  // the chip-domain loop holds a lane's eight samples and the next segment's loads
+#endif
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, bool CHIPS = false>
+__global__ __launch_bounds__(TRK_THREADS, CHIPS ? TRK_CHIPS_WAVES : TRK_WAVES) void trk_multicorrelator_kernel(
     const TrkChan* __restrict__ chans, const gc_epoch_params* __restrict__ params,
     float2* __restrict__ out, float2* __restrict__ partial,
     int n_channels, int n_epochs, int n_slices, int lds_table_floats)
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(TRK_THREADS, TRK_WAVES) void trk_multicorrelator_ke
 
     const TrkChan cd = chans[ch];
     const gc_epoch_params p = params[job];
-    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC, SC16>(cd, p, slice, n_slices, lds_table_floats, lds);
+    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC, SC16, TRK_THREADS, false, TRK_PF, CHIPS>(cd, p, slice, n_slices, lds_table_floats, lds);
     if (threadIdx.x < NTAPS)
         {
             if (n_slices == 1)
@@ -109,6 +112,20 @@ __global__ void trk_finish_kernel(const float2* __restrict__ partial, float2* __
 // -----------------------------------------------------------------------------
 // launcher
 // -----------------------------------------------------------------------------
+// $GNSSCORR_TRK_LOOP = samples | chips: which form of the plain float loop runs.  Default: samples -- the chip-domain form
+// (trk_chips.hpp) gives the same results and measured slower on MI355X in every mode of the bench
+static bool trk_chip_domain()
+{
+    static const bool on = [] {
+        const char* e = getenv("GNSSCORR_TRK_LOOP");
+        return e && e[0] == 'c';
+    }();
+    return on;
+}
+static size_t trk_chips_lds_bytes(int lds_table_floats)
+{
+    return (size_t)(TRK_HDR_FLOATS + ((lds_table_floats + 3) & ~3) + TRK_THREADS / 64 * TRK_CHIPS_WAVE_FLOATS) * sizeof(float);
+}
 template <int NTAPS, int FMT>
 static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStream_t st,
     const TrkChan* chans, const gc_epoch_params* params, float2* out, float2* partial,
@@ -117,6 +134,12 @@ static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStr
     switch (mode)
         {
         case TRK_MODE_PLAIN:
+            if (FMT == GC_IQ_F32 && trk_chip_domain() && trk_chips_lds_bytes(lds_table_floats) <= 64 * 1024)
+                {
+                    hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, GC_IQ_F32, false, false, true>), grid, dim3(TRK_THREADS),
+                        trk_chips_lds_bytes(lds_table_floats), st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+                    break;
+                }
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
                 chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
             break;
@@ -176,6 +199,10 @@ hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const
         break;
     switch (n_taps)
         {
+#ifdef TRK_DEV_BUILD  // development builds: the bench's tap counts only (a full build takes minutes)
+            CASE(3)
+            CASE(5)
+#else
             CASE(1)
             CASE(2)
             CASE(3)
@@ -184,6 +211,7 @@ hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const
             CASE(6)
             CASE(7)
             CASE(8)
+#endif
         default:
             return hipErrorInvalidValue;
         }

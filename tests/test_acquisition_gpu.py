@@ -374,6 +374,10 @@ def test_cfg4_full_width_32_prns_41_bins_2_dwells(gctx, oracle):
             _check(per_dwell[d][s], q, cfar=False)
             assert per_dwell[d][s].second_peak == pytest.approx(q.second_peak, rel=TOL)
         _check(last[s], q, cfar=False)
+        # the second search enqueued its dwells back to back: they ran as ONE pair (gc_acquisition.hip, inv_pending: one row pass over both
+        # dwells' spectra, one column pass that writes the grid once).  Same additions in the same order: not a bit may differ
+        a_, b_ = per_dwell[1][s], last[s]
+        assert (a_.indext, a_.doppler_hz, a_.mag, a_.test_statistics, a_.second_peak) == (b_.indext, b_.doppler_hz, b_.mag, b_.test_statistics, b_.second_peak)
     # a satellite of each batch, whole grid
     for s in (3, 29):
         ref = orcs[s].grid()
@@ -418,6 +422,63 @@ def test_uneven_satellite_batches(gctx, oracle, monkeypatch):
         assert np.max(np.abs(acq.grid(s) - ref)) <= TOL * ref.max()
     assert min(r.test_statistics for r in res[:4]) > max(r.test_statistics for r in res[4:])
     acq.close()
+
+
+@pytest.mark.parametrize("n_dwells", [2, 3, 4, 5])
+def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwells):
+    """Dwells enqueued back to back are searched in pairs (the first of a pair is held back until the second arrives; an odd one
+    and anything followed by a fetch run alone): 2 = one pair, 3 = pair + accumulating single, 4 = pair + accumulating pair,
+    5 = pair + pair + single.  An engine created with GNSSCORR_ACQ_FUSE=0 processes every dwell by itself, as acquisition_core does
+    (pcps_acquisition.cc:668-770): grids and results must be IDENTICAL, and the per-dwell engine is checked against the oracle."""
+    import gnsscorr
+    import torch
+    from helpers import synth_stream
+    fs, n = 4_000_000, 4000
+    prns = [3, 7, 11, 19, 23]
+    chips = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in prns[:3]]
+    x, _ = synth_stream(chips, fs, n_dwells * n, seed=500 + n_dwells, cn0_db_hz=(40.0, 46.0), doppler_max=2000.0)
+    c = _conf(fs, 1, 1, 4000.0, 2500, 500, max_dwells=n_dwells)
+    engines = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("GNSSCORR_ACQ_FUSE", fuse)
+        a = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
+        for s, prn in enumerate(prns):
+            a.set_local_code(s, oracle.gps_l1_ca_code_sampled(prn, fs))
+        engines.append(a)
+    d_x = torch.from_numpy(x.view(np.float32)).cuda()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    res = []
+    for a in engines:
+        a.reset()
+        for d in range(n_dwells):
+            a.dwell_enqueue(d_x.data_ptr() + 8 * n * d, st.cuda_stream)
+        res.append(a.fetch_results(st.cuda_stream))
+    for s, prn in enumerate(prns):
+        g1, g0 = engines[0].grid(s), engines[1].grid(s)
+        assert np.array_equal(g1, g0), (s, np.max(np.abs(g1 - g0)))
+        r1, r0 = res[0][s], res[1][s]
+        assert (r1.indext, r1.doppler_hz, r1.mag, r1.test_statistics, r1.second_peak) == (r0.indext, r0.doppler_hz, r0.mag, r0.test_statistics, r0.second_peak)
+        p = oracle.pcps(**c)
+        p.set_local_code(oracle.gps_l1_ca_code_sampled(prn, fs))
+        for d in range(n_dwells):
+            q = p.core(x[d * n:])
+        _check(r0, q, cfar=False)
+        assert r0.second_peak == pytest.approx(q.second_peak, rel=TOL)
+    # a held-back dwell is not lost when the caller looks before its partner arrives: fetch after the first dwell, then go on
+    a = engines[0]
+    a.reset()
+    a.dwell_enqueue(d_x.data_ptr(), st.cuda_stream)
+    first = a.fetch_results(st.cuda_stream)
+    b = engines[1]
+    b.reset()
+    b.dwell_enqueue(d_x.data_ptr(), st.cuda_stream)
+    assert [(r.indext, r.mag, r.test_statistics) for r in first] == [(r.indext, r.mag, r.test_statistics) for r in b.fetch_results(st.cuda_stream)]
+    a.dwell_enqueue(d_x.data_ptr() + 8 * n, st.cuda_stream)
+    b.dwell_enqueue(d_x.data_ptr() + 8 * n, st.cuda_stream)
+    assert np.array_equal(a.grid(0), b.grid(0))
+    for e in engines:
+        e.close()
 
 
 def test_gpu_grid_against_the_reference_matlab_analysis(gctx, oracle):

@@ -902,14 +902,17 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
             // butterfly q writes y[10 q + k]: the pair's 20 outputs are contiguous in each plane
             float* yr = pre + row * N2 + R * u;
             float* yi = pim + row * N2 + R * u;
-#pragma unroll
-            for (int k = 0; k < R; k += 2)
-                {
-                    *reinterpret_cast<acq_pk2*>(yr + k) = acq_pk2{a[k].r.x, a[k + 1].r.x};
-                    *reinterpret_cast<acq_pk2*>(yi + k) = acq_pk2{a[k].i.x, a[k + 1].i.x};
-                    *reinterpret_cast<acq_pk2*>(yr + R + k) = acq_pk2{a[k].r.y, a[k + 1].r.y};
-                    *reinterpret_cast<acq_pk2*>(yi + R + k) = acq_pk2{a[k].i.y, a[k + 1].i.y};
-                }
+            // as 16-byte stores: the lanes are 80 bytes apart, which 8-byte stores hit two-way bank conflicts with and 16-byte stores do not
+            *reinterpret_cast<acq_f32x4*>(yr + 0) = acq_f32x4{a[0].r.x, a[1].r.x, a[2].r.x, a[3].r.x};
+            *reinterpret_cast<acq_f32x4*>(yr + 4) = acq_f32x4{a[4].r.x, a[5].r.x, a[6].r.x, a[7].r.x};
+            *reinterpret_cast<acq_f32x4*>(yr + 8) = acq_f32x4{a[8].r.x, a[9].r.x, a[0].r.y, a[1].r.y};
+            *reinterpret_cast<acq_f32x4*>(yr + 12) = acq_f32x4{a[2].r.y, a[3].r.y, a[4].r.y, a[5].r.y};
+            *reinterpret_cast<acq_f32x4*>(yr + 16) = acq_f32x4{a[6].r.y, a[7].r.y, a[8].r.y, a[9].r.y};
+            *reinterpret_cast<acq_f32x4*>(yi + 0) = acq_f32x4{a[0].i.x, a[1].i.x, a[2].i.x, a[3].i.x};
+            *reinterpret_cast<acq_f32x4*>(yi + 4) = acq_f32x4{a[4].i.x, a[5].i.x, a[6].i.x, a[7].i.x};
+            *reinterpret_cast<acq_f32x4*>(yi + 8) = acq_f32x4{a[8].i.x, a[9].i.x, a[0].i.y, a[1].i.y};
+            *reinterpret_cast<acq_f32x4*>(yi + 12) = acq_f32x4{a[2].i.y, a[3].i.y, a[4].i.y, a[5].i.y};
+            *reinterpret_cast<acq_f32x4*>(yi + 16) = acq_f32x4{a[6].i.y, a[7].i.y, a[8].i.y, a[9].i.y};
         }
     __syncthreads();
     // ---- stage 2: S = 10, M = 10; u = 10 q + r, the pair shares q; inputs x[r + 10 q + 100 j] ----

@@ -72,6 +72,14 @@ struct gc_acq
     int inv_n_bins = 0;
     hipStream_t inv_stream = nullptr;
     bool fuse_dwells = true;  // $GNSSCORR_ACQ_FUSE=0: every dwell on its own
+    // Experiment, off by default ($GNSSCORR_ACQ_OVERLAP=1): row pass (instruction- and LDS-bound, 3.8 TB/s) and column pass (bandwidth-
+    // bound, 5.6 TB/s) of DIFFERENT satellite batches side by side -- rows on the caller's stream, columns on a stream of the engine,
+    // d_Q double-buffered, events both ways.  Measured 0.42 instead of 0.355 ms per search: the row pass holds all the LDS of every CU
+    // (4 x 40 KB), so the column workgroups do not become resident beside it and the eight cross-queue hand-overs only add latency
+    bool overlap = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
+    size_t q_stride = 0;      // float2 elements between the two halves of d_Q (0: single buffer)
 };
 
 static hipError_t acq_flush_inverse(gc_acq* a, hipStream_t st);
@@ -115,6 +123,12 @@ static void acq_release(gc_acq* a)
     (void)hipFree(a->d_part_val);
     (void)hipFree(a->d_part_cnt);
     if (a->h_results) (void)hipHostFree(a->h_results);
+    for (int i = 0; i < 2; i++)
+        {
+            if (a->ev_rows[i]) (void)hipEventDestroy(a->ev_rows[i]);
+            if (a->ev_cols[i]) (void)hipEventDestroy(a->ev_cols[i]);
+        }
+    if (a->side) (void)hipStreamDestroy(a->side);
 }
 
 // The wipe-off tables are kept in the row-permuted layout the forward row pass reads (P[bin][a][b] = wipe[bin][a + N1 * b]): the
@@ -237,7 +251,19 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     ACQ_TRY(hipMalloc(&a->d_xw, (size_t)a->n_bins_alloc * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_X, (size_t)2 * a->n_bins_alloc * N * sizeof(float2)));  // two dwells' spectra (see inv_pending)
     if (const char* e = std::getenv("GNSSCORR_ACQ_FUSE")) a->fuse_dwells = std::atoi(e) != 0;
-    ACQ_TRY(hipMalloc(&a->d_Q, q_cells * N * sizeof(float2)));
+    if (const char* e = std::getenv("GNSSCORR_ACQ_OVERLAP")) a->overlap = std::atoi(e) != 0;
+    if (a->overlap && a->sats_per_batch < n_sats)
+        {
+            // more than one batch: a second buffer, so that the rows of batch b + 1 run beside the columns of batch b
+            a->q_stride = q_cells * N;
+            ACQ_TRY(hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++)
+                {
+                    ACQ_TRY(hipEventCreateWithFlags(&a->ev_rows[i], hipEventDisableTiming));
+                    ACQ_TRY(hipEventCreateWithFlags(&a->ev_cols[i], hipEventDisableTiming));
+                }
+        }
+    ACQ_TRY(hipMalloc(&a->d_Q, (a->q_stride ? 2 : 1) * q_cells * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_grid, (size_t)n_sats * a->n_bins_alloc * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_tmp, (size_t)n_sats * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_blkv, (size_t)n_sats * a->n_bins_alloc * a->n_blocks * sizeof(float)));
@@ -289,6 +315,7 @@ gc_status gc_acq_destroy(gc_acq* a)
     if (!a) return GC_OK;
     gc_device_guard g(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->stream);
+    if (a->side) (void)hipStreamSynchronize(a->side);
     acq_release(a);
     delete a;
     return GC_OK;
@@ -420,11 +447,19 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
         per_batch = (a->n_sats + n_batches - 1) / n_batches;  // equal batches
     }
     hipError_t e = hipSuccess;
-    for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += per_batch)
+    const bool two_streams = a->q_stride != 0 && per_batch < a->n_sats;
+    int b = 0;
+    for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += per_batch, b++)
         {
             const int ns = std::min(per_batch, a->n_sats - s0);
-            e = acq_launch_rows(st, true, a->plan, ns * spectra, a->d_X, AcqCellMap{1, spectra}, a->d_codes + (size_t)s0 * N,
-                AcqCellMap{spectra, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
+            float2* Q = a->d_Q + (two_streams ? (size_t)(b & 1) * a->q_stride : 0);
+            hipStream_t cst = two_streams ? a->side : st;
+            if (two_streams && b >= 2) e = hipStreamWaitEvent(st, a->ev_cols[b & 1], 0);  // the columns of batch b - 2 have read this half
+            if (e == hipSuccess)
+                e = acq_launch_rows(st, true, a->plan, ns * spectra, a->d_X, AcqCellMap{1, spectra}, a->d_codes + (size_t)s0 * N,
+                    AcqCellMap{spectra, 1 << 30}, Q, a->d_wN2, a->d_wN);
+            if (e == hipSuccess && two_streams) e = hipEventRecord(a->ev_rows[b & 1], st);
+            if (e == hipSuccess && two_streams) e = hipStreamWaitEvent(cst, a->ev_rows[b & 1], 0);
             if (e != hipSuccess) break;
             AcqMagArgs m;
             m.grid = a->d_grid + (size_t)s0 * n_bins * N;
@@ -435,8 +470,11 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
             m.eff = (int)a->eff;
             m.n_bins = n_bins;
             m.tmp_bin = n_bins - 1;
-            e = acq_launch_cols(st, true, pair ? (accumulate ? ACQ_EPI_MAG2_ACC : ACQ_EPI_MAG2) : (accumulate ? ACQ_EPI_MAG_ACC : ACQ_EPI_MAG), a->plan, ns * n_bins, a->d_Q, nullptr, &m);
+            e = acq_launch_cols(cst, true, pair ? (accumulate ? ACQ_EPI_MAG2_ACC : ACQ_EPI_MAG2) : (accumulate ? ACQ_EPI_MAG_ACC : ACQ_EPI_MAG), a->plan, ns * n_bins, Q, nullptr, &m);
+            if (e == hipSuccess && two_streams) e = hipEventRecord(a->ev_cols[b & 1], cst);
         }
+    // everything behind this call on `st` sees the finished grid (the side stream runs its column passes in order: the last one's event covers all)
+    if (e == hipSuccess && two_streams && b > 0) e = hipStreamWaitEvent(st, a->ev_cols[(b - 1) & 1], 0);
     if (e == hipSuccess)
         {
             AcqFinalArgs f;

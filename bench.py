@@ -610,7 +610,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 # <NTAPS, HDR, HDC, FMT = GC_IQ_F32, CC, SC16>: the name rocprofv3 prints
-                "kernel": "trk_multicorrelator_kernel<3, false, false, 0, false, false>", "kernel_ms": kernel_ms,
+                "kernel": "trk_multicorrelator_kernel<3, false, false, 0, false, false, false>", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }

@@ -517,7 +517,12 @@ gc_status gc_acq_set_input_format(gc_acq* a, int iq_format);
 gc_status gc_acq_dwell_dev(gc_acq* a, const void* dev_iq, gc_acq_result* host_results, void* stream);
 gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_results);
 /* Enqueue-only variant for throughput runs: results stay in HBM until
- * gc_acq_fetch_results(). */
+ * gc_acq_fetch_results().  The input block has been consumed (in stream order) when the call returns its work to `stream`.
+ * Dwells of one search enqueued back to back on one stream are searched in PAIRS (pcps_acquisition.cc:730-739 adds the second
+ * |.|^2 to the first; here both are added in one pass and the grid is written once): the inverse passes of a dwell with
+ * dwell counter < max_dwells are held back until the next call on the handle -- an accumulating dwell joins it, anything else
+ * (fetch, grid read, new code, reset ...) first completes it alone or, for a reset, discards it.  Results and grids are bit-identical
+ * to per-dwell processing; $GNSSCORR_ACQ_FUSE=0 (read by gc_acq_create) turns the pairing off. */
 gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream);
 gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* stream);
 /* One dwell on the block of consumed_samples that starts at absolute sample first_index of the ring `s`

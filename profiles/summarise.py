@@ -14,7 +14,7 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 PASSES = sys.argv[2:] or ["full", "trk", "acq", "sq"]
-KERNEL = "trk_multicorrelator_kernel<3, false, false, 0, false, false>"
+KERNEL = "trk_multicorrelator_kernel<3, false, false, 0, false, false, false>"
 
 
 def counter_mean(path, counter):

@@ -424,6 +424,47 @@ def test_uneven_satellite_batches(gctx, oracle, monkeypatch):
     acq.close()
 
 
+def _pairs_with_small_buffer_and_cshort_input(gctx, oracle, monkeypatch):
+    """The pair path where it splits differently from the per-dwell path: a 1 MB inter-pass buffer holds three satellites of one
+    dwell but only ONE satellite pair-wise (7 batches instead of 3 + 3 + 1), input blocks are lv_16sc_t (converted per dwell), the
+    second search changes a code in between (the held-back dwell must be searched with the code of its time)."""
+    import gnsscorr
+    import torch
+    from helpers import synth_stream
+    fs, n = 4_000_000, 4000
+    prns = [2, 5, 9, 14, 21, 27, 30]
+    chips = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in prns[:4]]
+    x, _ = synth_stream(chips, fs, 3 * n, seed=91, cn0_db_hz=(44.0, 50.0), doppler_max=2000.0)
+    xi = np.clip(np.round(x.view(np.float32) * 200.0), -32768, 32767).astype(np.int16)
+    c = _conf(fs, 1, 1, 4000.0, 2500, 500, max_dwells=3)
+    monkeypatch.setenv("GNSSCORR_ACQ_Q_MB", "1")
+    eng = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("GNSSCORR_ACQ_FUSE", fuse)
+        a = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
+        a.set_input_format(gnsscorr.GC_IQ_I16)
+        for s_, prn in enumerate(prns):
+            a.set_local_code(s_, oracle.gps_l1_ca_code_sampled(prn, fs))
+        eng.append(a)
+    d_x = torch.from_numpy(xi).cuda()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    out = []
+    for a in eng:
+        a.reset()
+        a.dwell_enqueue(d_x.data_ptr(), st.cuda_stream)
+        a.set_local_code(6, oracle.gps_l1_ca_code_sampled(31, fs))  # between the dwells of what would have been a pair
+        a.dwell_enqueue(d_x.data_ptr() + 4 * n, st.cuda_stream)
+        a.dwell_enqueue(d_x.data_ptr() + 8 * n, st.cuda_stream)
+        out.append(a.fetch_results(st.cuda_stream))
+    for s_ in range(len(prns)):
+        assert np.array_equal(eng[0].grid(s_), eng[1].grid(s_)), s_
+        r1, r0 = out[0][s_], out[1][s_]
+        assert (r1.indext, r1.doppler_hz, r1.mag, r1.test_statistics) == (r0.indext, r0.doppler_hz, r0.mag, r0.test_statistics)
+    for a in eng:
+        a.close()
+
+
 @pytest.mark.parametrize("n_dwells", [2, 3, 4, 5])
 def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwells):
     """Dwells enqueued back to back are searched in pairs (the first of a pair is held back until the second arrives; an odd one
@@ -465,6 +506,8 @@ def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwe
             q = p.core(x[d * n:])
         _check(r0, q, cfar=False)
         assert r0.second_peak == pytest.approx(q.second_peak, rel=TOL)
+    if n_dwells == 3:
+        _pairs_with_small_buffer_and_cshort_input(gctx, oracle, monkeypatch)
     # a held-back dwell is not lost when the caller looks before its partner arrives: fetch after the first dwell, then go on
     a = engines[0]
     a.reset()

@@ -195,6 +195,11 @@ def main():
         prn = gid % 32 + 1
         code = gps_ca_code(prn)
         x, truth = make_channel_stream(torch, dev, code, n_stream, seed=1002 + 7 * gid)
+        stagger = int(os.environ.get("BENCH_STAGGER_SAMPLES", "0"))  # experiment: start channel ch's buffer ch * stagger samples into its allocation
+        if stagger:
+            hold = torch.empty(n_stream + ch * stagger + 16, 2, device=dev, dtype=torch.float32)
+            hold[ch * stagger:ch * stagger + n_stream] = x
+            x = hold[ch * stagger:ch * stagger + n_stream]
         streams.append(x)
         truths.append(truth)
         codes.append(code)

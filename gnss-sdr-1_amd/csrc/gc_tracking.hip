@@ -398,7 +398,7 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
                 }
         }
     hipError_t e = trk_launch(b->n_taps, b->mode, b->iq_format, st, b->d_chans, dev_params, static_cast<float2*>(dev_out), b->d_partial,
-        b->n_channels, n_epochs, n_slices, b->lds_table_floats);
+        b->n_channels, n_epochs, n_slices, b->lds_table_floats, true);
     if (e != hipSuccess)
         {
             cancel_all();
@@ -919,7 +919,7 @@ static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>
         }
     const double tb = l1_now_us();
     if (e == hipSuccess)
-        e = trk_launch(k.n_corr, k.mode, k.fmt, lane.stream, lane.dv_chans, lane.dv_params, lane.dv_out, lane.d_partial, B, 1, k.n_slices, lds_floats);
+        e = trk_launch(k.n_corr, k.mode, k.fmt, lane.stream, lane.dv_chans, lane.dv_params, lane.dv_out, lane.d_partial, B, 1, k.n_slices, lds_floats, false);
     const double tc = l1_now_us();
     if (e == hipSuccess) e = hipStreamSynchronize(lane.stream);
     const double td = l1_now_us();
@@ -1200,7 +1200,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     if (!zc) GC_HIP(hipMemcpyAsync(c->d_stage, s, sizeof *s, hipMemcpyHostToDevice, st));
     gc_correlator::Staging* stage_dev = zc ? c->dv_stage : c->d_stage;
     hipError_t e = trk_launch(c->n_corr, mode, sc16 ? GC_IQ_I16 : GC_IQ_F32, st, &stage_dev->chan, &stage_dev->params, zc ? c->dv_out : c->d_out, c->d_partial, 1, 1,
-        n_slices, per_chip * (L + 64));
+        n_slices, per_chip * (L + 64), false);
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "tracking kernel launch failed: %s", hipGetErrorString(e));
     if (!zc) GC_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, st));
     GC_HIP(hipStreamSynchronize(st));

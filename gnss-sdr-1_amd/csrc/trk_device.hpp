@@ -20,7 +20,13 @@ static constexpr __host__ __device__ int trk_hdr_floats(int threads) { return th
 #define TRK_PF 2  // chunks prefetched ahead of the one being processed (16-byte loads in flight per lane)
 #endif
 #ifndef TRK_NT
-#define TRK_NT 0  // 1: nontemporal IQ loads
+#define TRK_NT 1  // nontemporal IQ loads (0: plain): the stream is read once; with line-aligned chunks +5-7 % on the HBM-bound launch (alone: +1.5 %)
+#endif
+#ifndef TRK_PRELOAD
+#define TRK_PRELOAD 0  // the first two chunks of a window are requested before the workgroup's prologue (0: at the start of the loop)
+#endif
+#ifndef TRK_ALIGN_PAIRS
+#define TRK_ALIGN_PAIRS 8  // alignment, in sample pairs, of the address the chunks of a window are counted from (1 or 8)
 #endif
 
 static __device__ __forceinline__ int posmod(int i, int L)
@@ -148,6 +154,19 @@ static __device__ __forceinline__ int floor_to_int(float x)
     return i;
 }
 
+// one lane's 16-byte piece (two samples) of chunk c: uniform chunk base + constant per-lane offset, SGPR-base global load
+template <int FMT, int THREADS>
+static __device__ __forceinline__ f32x4 trk_load_chunk(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, int c)
+{
+    typedef typename IqFmt<FMT>::pair pair_t;
+    const GC_GLOBAL char* p = reinterpret_cast<const GC_GLOBAL char*>(base) + (size_t)c * (THREADS * sizeof(pair_t)) + threadIdx.x * sizeof(pair_t);
+#if TRK_NT
+    return IqFmt<FMT>::cvt(__builtin_nontemporal_load(reinterpret_cast<const GC_GLOBAL pair_t*>(p)));
+#else
+    return IqFmt<FMT>::cvt(*reinterpret_cast<const GC_GLOBAL pair_t*>(p));
+#endif
+}
+
 // Main loop over the chunks [c0, c1) of one (channel, epoch, slice).
 //   WINDOWED: table[] holds code[(lo + k) mod L], indices need no wrap
 //   else    : table[] holds code[0..L), indices are wrapped with the reference's modulo
@@ -168,8 +187,13 @@ template <int NTAPS, bool HDR, bool HDC, bool WINDOWED, int FMT, bool CC = false
 static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<FMT>::elem* __restrict__ base, const float* __restrict__ table,
     int a, int N, int V, int c0, int c1, int lo, int L, float step, float rem, float rate,
     const float (&shifts)[NTAPS], const int (&tap_delay)[NTAPS], double theta0, double dtheta, double drate, float lnmod,
-    float (&accr)[NTAPS + (DATA ? 1 : 0)], float (&acci)[NTAPS + (DATA ? 1 : 0)], const float* __restrict__ table2 = nullptr)
+    float (&accr)[NTAPS + (DATA ? 1 : 0)], float (&acci)[NTAPS + (DATA ? 1 : 0)], const float* __restrict__ table2,
+    int lc0, int lc1, f32x4 pre0, f32x4 pre1)
 {
+    // lc0, lc1: chunks [lc0, lc1) lie inside the channel's buffer as WHOLE chunks (the ragged first / last chunk of a window usually
+    // does: its neighbours in the stream are there), so they are fetched like the others -- 16-byte loads, prefetched -- and the
+    // samples outside the window zeroed in registers; pre0 / pre1: chunks c0 and c0 + 1 where they are such chunks, requested by
+    // the caller before its prologue (window fill, carrier angles), which then overlaps their latency
     static_assert(!DATA || (!CC && !SC16), "the data-component correlator exists for real float replicas only");
     constexpr int CHUNK = 2 * THREADS;
     constexpr int PT = NTAPS / 2;  // prompt tap of E/P/L and VE/E/P/L/VL
@@ -227,15 +251,19 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     // masks, no clamps.  Only the first chunk (odd-aligned window) and the last one can be ragged; they
     // are processed outside the pipelined interior loop.
     auto chunk_is_full = [&](int c) { return (c > 0 || a == 0) && (c + 1) * CHUNK <= V; };
-    auto load_full = [&](int c) -> f32x4 {
-        // uniform chunk base + constant per-lane offset: SGPR-base global loads
-        typedef typename IqFmt<FMT>::pair pair_t;
-        const GC_GLOBAL char* p = reinterpret_cast<const GC_GLOBAL char*>(base) + (size_t)c * (CHUNK / 2 * sizeof(pair_t)) + tid * sizeof(pair_t);
-#if TRK_NT
-        return IqFmt<FMT>::cvt(__builtin_nontemporal_load(reinterpret_cast<const GC_GLOBAL pair_t*>(p)));
-#else
-        return IqFmt<FMT>::cvt(*reinterpret_cast<const GC_GLOBAL pair_t*>(p));
-#endif
+    // a chunk that may be fetched whole: every full chunk (it lies inside the window, mirror of a ring included), and the ragged ones
+    // the caller found inside the buffer
+    auto loadable = [&](int c) { return chunk_is_full(c) || (c >= lc0 && c < lc1); };
+    auto load_full = [&](int c) -> f32x4 { return trk_load_chunk<FMT, THREADS>(base, c); };
+    // a whole chunk's piece with the samples outside the window zeroed
+    auto mask_window = [&](int c, f32x4 x) -> f32x4 {
+        const int v = c * CHUNK + tid * 2;
+        const bool in0 = v >= a && v < V, in1 = v + 1 >= a && v + 1 < V;
+        x.x = in0 ? x.x : 0.f;
+        x.y = in0 ? x.y : 0.f;
+        x.z = in1 ? x.z : 0.f;
+        x.w = in1 ? x.w : 0.f;
+        return x;
     };
     auto load_masked = [&](int c) -> f32x4 {
         const int v = c * CHUNK + tid * 2;
@@ -378,12 +406,16 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     };
 
     if (c0 >= c1) return;
+#if !TRK_PRELOAD
+    if (loadable(c0)) pre0 = load_full(c0);
+    if (c0 + 1 < c1 && loadable(c0 + 1)) pre1 = load_full(c0 + 1);
+#endif
     int c = c0;
     // ---- ragged head (at most one chunk) ----
     if (!chunk_is_full(c))
         {
             resync(c);
-            process(std::false_type{}, c, load_masked(c));
+            process(std::false_type{}, c, loadable(c) ? mask_window(c, pre0) : load_masked(c));
             ++c;
         }
     // ---- interior: full chunks, TRK_PF loads in flight ahead of the chunk being processed ----
@@ -392,13 +424,15 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
         {
             // two loads in flight per lane; the loop is unrolled by two so that the buffers keep their
             // registers (a rotating queue would have to wait for the youngest load to move it)
-            // prefetches past the end re-read the last full chunk (in bounds, value unused): no branch
+            // prefetches past the end re-read the last chunk that may be fetched whole (the ragged tail where it is one: its lines
+            // are then on their way when the tail asks for them; else the last full chunk; value unused): no branch
             // in the loop body, so the compiler can wait with vmcnt(1) and keep one load in flight
-            const int clast = cf1 - 1;
+            const int clast = (cf1 < c1 && loadable(cf1)) ? cf1 : cf1 - 1;
             if constexpr (PF == 2)
                 {
-                    f32x4 x0 = load_full(c);
-                    f32x4 x1 = load_full(min(c + 1, clast));
+                    // chunks c0 and c0 + 1 were requested by the caller where they may be fetched whole
+                    f32x4 x0 = (c == c0) ? pre0 : (loadable(c0 + 1) ? pre1 : load_full(c));
+                    f32x4 x1 = (c == c0 && c0 + 1 < c1 && loadable(c0 + 1)) ? pre1 : load_full(min(c + 1, clast));
                     while (c < cf1)
                         {
                             if ((c - c0) % TRK_RESYNC == 0) resync(c);
@@ -461,7 +495,8 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
     if (c < c1)
         {
             if ((c - c0) % TRK_RESYNC == 0) resync(c);
-            process(std::false_type{}, c, load_masked(c));
+            // (a window of two ragged chunks and nothing between them finds its tail in pre1)
+            process(std::false_type{}, c, loadable(c) ? mask_window(c, (c == c0 + 1 && PF == 2) ? pre1 : load_full(c)) : load_masked(c));
         }
 }
 
@@ -477,7 +512,7 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 // floats of LDS behind the code window (rounded up to 16 bytes)
 template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF, bool CHIPS = false>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
-    int lds_table_floats, float* lds)
+    int lds_table_floats, float* lds, int align_pairs = TRK_ALIGN_PAIRS)
 {
     // lds[0..HDRF): header (wave partials); then the code window
     static_assert(!CHIPS || (!HDR && !HDC && !CC && !SC16 && FMT == GC_IQ_F32), "the chip-domain loop exists for the plain float correlator");
@@ -490,14 +525,35 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
 
     typedef typename IqFmt<FMT>::elem elem_t;
     const elem_t* iq = static_cast<const elem_t*>(cd.iq) + (cd.ring_len ? p.sample_offset % cd.ring_len : p.sample_offset);
-    const int a = (int)((reinterpret_cast<uintptr_t>(iq) / sizeof(elem_t)) & 1);  // 1: window starts on the odd half of a sample pair
-    // pair-aligned; sample n lives at base[n + a].  IQ lives in HBM: global (not flat) loads
+    // samples between the aligned address the chunks are counted from and the window's first one (they are masked out of the first
+    // chunk): one pair keeps the pair loads legal, eight pairs of float samples (128 bytes) also keep every wave-instruction's 1 KiB on
+    // eight cache lines instead of nine
+    // (align_pairs = 1 for the level-1 calls: their staging keeps a window's 16-byte phase, and with it the summation order and the
+    // bits of the result, whether the call runs alone or in a batch)
+    const int a = (int)((reinterpret_cast<uintptr_t>(iq) / sizeof(elem_t)) & (2 * align_pairs - 1));
+    // sample n lives at base[n + a].  IQ lives in HBM: global (not flat) loads
     const GC_GLOBAL elem_t* base = (const GC_GLOBAL elem_t*)(iq - a);
     const int V = N + a;
     const int n_chunks = (V + CHUNK - 1) / CHUNK;
     const int cps = (n_chunks + n_slices - 1) / n_slices;
     const int c0 = slice * cps;
     const int c1 = min(n_chunks, c0 + cps);
+    // Chunks [lc0, lc1) lie inside the channel's buffer as whole chunks: the ragged ends of a window are then fetched like its
+    // interior (trk_loop).  The first two chunks are requested HERE, before the prologue below, which hides their latency.
+    int lc0 = 0, lc1 = 0;
+    f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f};
+    if (!CHIPS)
+        {
+            const unsigned long long off = cd.ring_len ? p.sample_offset % cd.ring_len : p.sample_offset;
+            const unsigned long long end = cd.ring_len ? (unsigned long long)cd.ring_len : cd.n_iq;  // samples at cd.iq (a ring's mirror is not counted)
+            const unsigned long long room = end > off ? end - off : 0;
+            lc0 = off >= (unsigned long long)a ? 0 : 1;
+            lc1 = (int)min((unsigned long long)n_chunks, (room + (unsigned long long)a) / CHUNK);
+#if TRK_PRELOAD
+            if (c0 < c1 && c0 >= lc0 && c0 < lc1) pre0 = trk_load_chunk<FMT, THREADS>(base, c0);
+            if (c0 + 1 < c1 && c0 + 1 >= lc0 && c0 + 1 < lc1) pre1 = trk_load_chunk<FMT, THREADS>(base, c0 + 1);
+#endif
+        }
 
     const float step = p.code_phase_step_chips;
     const float rem = p.rem_code_phase_chips;
@@ -647,9 +703,9 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
                 trk_loop_chips<NTAPS, false, THREADS, DATA>(base, table, table2, a, N, V, c0, c1, 0, L, step, rem, shifts, theta0, dtheta, scratch, accr, acci);
         }
     else if (windowed)
-        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
+        trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2, lc0, lc1, pre0, pre1);
     else
-        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2);
+        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA, PF>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2, lc0, lc1, pre0, pre1);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread

@@ -32,8 +32,11 @@ enum
 // Enqueues the multicorrelator for n_channels x n_epochs jobs on `st`.
 // lds_table_floats: capacity of the LDS code window in floats (>= longest code_len; twice that for complex chips).
 // partial: workspace of n_channels*n_epochs*n_slices*n_taps float2 (n_slices > 1 only).
+// line_aligned: the chunks of a window are counted from the 128-byte boundary below its first sample (whole cache lines per wave
+// instruction: the streaming launches) instead of the 16-byte one (the level-1 calls, whose staging keeps a window's 16-byte phase so
+// that a call gives the same bits alone and in a batch).
 hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const TrkChan* chans,
     const gc_epoch_params* params, float2* out, float2* partial,
-    int n_channels, int n_epochs, int n_slices, int lds_table_floats);
+    int n_channels, int n_epochs, int n_slices, int lds_table_floats, bool line_aligned);
 
 #endif

@@ -34,7 +34,7 @@ template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = f
 __global__ __launch_bounds__(TRK_THREADS, CHIPS ? TRK_CHIPS_WAVES : TRK_WAVES) void trk_multicorrelator_kernel(
     const TrkChan* __restrict__ chans, const gc_epoch_params* __restrict__ params,
     float2* __restrict__ out, float2* __restrict__ partial,
-    int n_channels, int n_epochs, int n_slices, int lds_table_floats)
+    int n_channels, int n_epochs, int n_slices, int lds_table_floats, int align_pairs)
 {
     extern __shared__ float lds[];
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TRK_THREADS, CHIPS ? TRK_CHIPS_WAVES : TRK_WAVES) v
 
     const TrkChan cd = chans[ch];
     const gc_epoch_params p = params[job];
-    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC, SC16, TRK_THREADS, false, TRK_PF, CHIPS>(cd, p, slice, n_slices, lds_table_floats, lds);
+    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC, SC16, TRK_THREADS, false, TRK_PF, CHIPS>(cd, p, slice, n_slices, lds_table_floats, lds, align_pairs);
     if (threadIdx.x < NTAPS)
         {
             if (n_slices == 1)
@@ -129,7 +129,7 @@ static size_t trk_chips_lds_bytes(int lds_table_floats)
 template <int NTAPS, int FMT>
 static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStream_t st,
     const TrkChan* chans, const gc_epoch_params* params, float2* out, float2* partial,
-    int n_channels, int n_epochs, int n_slices, int lds_table_floats)
+    int n_channels, int n_epochs, int n_slices, int lds_table_floats, int align_pairs)
 {
     switch (mode)
         {
@@ -137,28 +137,28 @@ static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStr
             if (FMT == GC_IQ_F32 && trk_chip_domain() && trk_chips_lds_bytes(lds_table_floats) <= 64 * 1024)
                 {
                     hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, GC_IQ_F32, false, false, true>), grid, dim3(TRK_THREADS),
-                        trk_chips_lds_bytes(lds_table_floats), st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+                        trk_chips_lds_bytes(lds_table_floats), st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
                     break;
                 }
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
-                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
             break;
         case TRK_MODE_HD_RESAMPLER:
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, true, false, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
-                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
             break;
         case TRK_MODE_HD_FULL:
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, true, true, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
-                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
             break;
         case TRK_MODE_COMPLEX_CODE:
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, FMT, true>), grid, dim3(TRK_THREADS), lds_bytes, st,
-                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
             break;
         case TRK_MODE_SC16:
             if (FMT != GC_IQ_I16) return hipErrorInvalidValue;  // lv_16sc_t in, lv_16sc_t out
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, GC_IQ_I16, false, true>), grid, dim3(TRK_THREADS), lds_bytes, st,
-                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+                chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
             break;
         default:
             return hipErrorInvalidValue;
@@ -169,16 +169,16 @@ static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStr
 template <int NTAPS>
 static hipError_t launch_ntaps(int mode, int fmt, dim3 grid, size_t lds_bytes, hipStream_t st,
     const TrkChan* chans, const gc_epoch_params* params, float2* out, float2* partial,
-    int n_channels, int n_epochs, int n_slices, int lds_table_floats)
+    int n_channels, int n_epochs, int n_slices, int lds_table_floats, int align_pairs)
 {
     switch (fmt)
         {
         case GC_IQ_F32:
-            return launch_ntaps_fmt<NTAPS, GC_IQ_F32>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+            return launch_ntaps_fmt<NTAPS, GC_IQ_F32>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
         case GC_IQ_I16:
-            return launch_ntaps_fmt<NTAPS, GC_IQ_I16>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+            return launch_ntaps_fmt<NTAPS, GC_IQ_I16>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
         case GC_IQ_I8:
-            return launch_ntaps_fmt<NTAPS, GC_IQ_I8>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats);
+            return launch_ntaps_fmt<NTAPS, GC_IQ_I8>(mode, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
         default:
             return hipErrorInvalidValue;
         }
@@ -186,8 +186,9 @@ static hipError_t launch_ntaps(int mode, int fmt, dim3 grid, size_t lds_bytes, h
 
 hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const TrkChan* chans,
     const gc_epoch_params* params, float2* out, float2* partial,
-    int n_channels, int n_epochs, int n_slices, int lds_table_floats)
+    int n_channels, int n_epochs, int n_slices, int lds_table_floats, bool line_aligned)
 {
+    const int align_pairs = line_aligned ? TRK_ALIGN_PAIRS : 1;
     const int epochs8 = n_epochs == 1 ? 1 : (n_epochs + 7) / 8 * 8;
     dim3 grid((unsigned)((size_t)epochs8 * n_channels * n_slices));
     size_t lds_bytes = (size_t)(TRK_HDR_FLOATS + lds_table_floats) * sizeof(float);
@@ -195,7 +196,7 @@ hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const
 #define CASE(NT)                                                                                       \
     case NT:                                                                                           \
         e = launch_ntaps<NT>(mode, iq_format, grid, lds_bytes, st, chans, params, out, partial, n_channels, n_epochs, \
-            n_slices, lds_table_floats);                                                               \
+            n_slices, lds_table_floats, align_pairs);                                                  \
         break;
     switch (n_taps)
         {

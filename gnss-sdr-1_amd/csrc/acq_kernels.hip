@@ -1154,6 +1154,10 @@ static __device__ __forceinline__ MaxPair max_pair(MaxPair a, MaxPair b)
 #define ACQ_COLS_WAVES 1  // minimum waves per SIMD the columns kernel is compiled for.  4 (128 registers, a fourth workgroup per CU) was
                           // measured: the 25-point column transform then spills 43 registers and a search takes 0.60 instead of 0.50 ms
 #endif
+#ifndef ACQ_COLS_NT
+#define ACQ_COLS_NT 2  // bit 0: streaming loads of the inter-pass buffer (measured SLOWER, 0.381 vs 0.345 ms per search: much of it is served by
+                       // the Infinity Cache and the hint gives that up); bit 1: streaming stores of the magnitude grid (0.340 vs 0.345 ms)
+#endif
 #ifndef ACQ_COLS_PAIR_WAVES
 #define ACQ_COLS_PAIR_WAVES 3  // the two-dwell epilogue is held to the registers of the one-dwell kernel (168: three waves per SIMD)
 #endif
@@ -1170,8 +1174,21 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
     constexpr bool PAIR = (EPI == ACQ_EPI_MAG2 || EPI == ACQ_EPI_MAG2_ACC);
     const size_t qcell = PAIR ? (size_t)(cell / mag.n_bins) * (2 * mag.n_bins) + cell % mag.n_bins : (size_t)cell;
     const float2* q = Q + qcell * N;
+    // the inter-pass buffer is read exactly once (here): streaming loads when ACQ_COLS_NT & 1; the magnitude grid is written once per
+    // search: streaming stores when ACQ_COLS_NT & 2
+    auto ldq = [](const float2* p) -> float2 {
+#if ACQ_COLS_NT & 1
+        if (EPI >= ACQ_EPI_MAG)
+            {
+                typedef float nt_f2 __attribute__((ext_vector_type(2)));
+                const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(p));
+                return make_float2(v.x, v.y);
+            }
+#endif
+        return *p;
+    };
 #pragma unroll
-    for (int k = 0; k < N1; k++) v0[k] = active ? q[(size_t)k * N2 + n2] : make_float2(0.f, 0.f);
+    for (int k = 0; k < N1; k++) v0[k] = active ? ldq(q + (size_t)k * N2 + n2) : make_float2(0.f, 0.f);
     RegFft<N1, 1, N1, INV>::run(v0, v1, plan.w1);
     float2* res = RegFft<N1, 1, N1, INV>::result_in_first ? v0 : v1;
     // first dwell's magnitudes wait in LDS (N1 x 256 floats: 25 KB of the 160) while the second column is transformed: in
@@ -1184,7 +1201,7 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
             __builtin_amdgcn_sched_barrier(0);
             const float2* q2 = q + (size_t)mag.n_bins * N;
 #pragma unroll
-            for (int k = 0; k < N1; k++) v0[k] = active ? q2[(size_t)k * N2 + n2] : make_float2(0.f, 0.f);
+            for (int k = 0; k < N1; k++) v0[k] = active ? ldq(q2 + (size_t)k * N2 + n2) : make_float2(0.f, 0.f);
             RegFft<N1, 1, N1, INV>::run(v0, v1, plan.w1);
         }
 
@@ -1256,7 +1273,11 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
                                             if (tmp) tmp[idx] = p;
                                             val = prev[HAS_PREV ? k : 0] + p;
                                         }
+#if ACQ_COLS_NT & 2
+                                    __builtin_nontemporal_store(val, &g[idx]);
+#else
                                     g[idx] = val;
+#endif
                                     MaxPair c = {val, (unsigned)idx};
                                     best = max_pair(best, c);
                                 }

@@ -810,6 +810,9 @@ static __device__ __forceinline__ void pk_powers10(VC<V> w, VC<V>* tw)
 #ifndef ACQ_ROWS3_DBG
 #define ACQ_ROWS3_DBG 0  // 1: compile the phase-elimination switches of $GNSSCORR_ACQ_DBG in (profiles/tools/rows3_phases.sh builds with it)
 #endif
+#ifndef ACQ_ROWS3_NT
+#define ACQ_ROWS3_NT 0  // 1: streaming stores of the inter-pass buffer
+#endif
 #ifndef ACQ_ROWS3_WAVES
 #define ACQ_ROWS3_WAVES 4
 #endif
@@ -963,7 +966,11 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
             for (int k = 0; k < R; k++)
                 {
                     const PkC o = pk_tmul<INV>(a[k], k == 0 ? bb : pk_mul(bb, tw[k]));
+#if ACQ_ROWS3_NT
+                    if (!(ACQ_ROWS3_DBG && (g.dbg & 2)) || o.r.x == 1.2345e-33f) __builtin_nontemporal_store(acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y}, reinterpret_cast<acq_f32x4*>(qp + 100 * k));
+#else
                     if (!(ACQ_ROWS3_DBG && (g.dbg & 2)) || o.r.x == 1.2345e-33f) *reinterpret_cast<acq_f32x4*>(qp + 100 * k) = acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y};
+#endif
                 }
         }
     __syncthreads();  // stage 3 has read the planes: the next group's stage 1 may overwrite them

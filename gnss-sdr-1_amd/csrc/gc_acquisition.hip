@@ -61,9 +61,10 @@ struct gc_acq
     bool final_pending = false;
     AcqFinalArgs final_args{};
     hipStream_t final_stream = nullptr;
-    // The inverse passes of a dwell that more dwells are expected to follow (dwell counter < max_dwells, plain statistic) are held
-    // back, its spectra parked in slot 0 of d_X: if the next call is an accumulating dwell on the same stream, BOTH dwells go through
-    // one row pass over 2 * n_bins spectra per satellite and one column pass that adds the two |.|^2 and writes the grid once
+    // Of a dwell that more dwells are expected to follow (dwell counter < max_dwells, plain statistic) only the input block is taken
+    // at once (row-permuted into slot 0 of d_xw); its transforms are held back: if the next call is an accumulating dwell on the same
+    // stream, BOTH blocks go through one forward row / column pass (2 * n_bins spectra into d_X), one inverse row pass over
+    // 2 * n_bins spectra per satellite and one column pass that adds the two |.|^2 and writes the grid once
     // (ACQ_EPI_MAG2) -- the grid read-modify-write of the second dwell and the first dwell's grid write never happen.  Anything
     // else (a fetch, a grid read, a change of codes or of the Doppler grid) first runs the held-back passes alone, so every caller
     // sees what per-dwell processing would have produced; gc_acq_reset() drops them with the grid.
@@ -505,6 +506,17 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
     return e;
 }
 
+// FFT(x * wipeoff[d]) of `n_blocks` input blocks parked (row-permuted) in d_xw -> d_X[block][bin]: x * wipeoff[d]
+// (pcps_acquisition.cc:717) is the two-operand load of the forward row pass (:721), shared by every satellite
+static hipError_t acq_forward(gc_acq* a, hipStream_t st, int n_blocks)
+{
+    const int n_bins = (int)a->n_bins;
+    hipError_t e = acq_launch_rows(st, false, a->plan, n_blocks * n_bins, a->d_wipe, AcqCellMap{1, n_bins}, a->d_xw, AcqCellMap{n_bins, 1 << 30},
+        a->d_Q, a->d_wN2, a->d_wN);
+    if (e == hipSuccess) e = acq_launch_cols(st, false, ACQ_EPI_PERM, a->plan, n_blocks * n_bins, a->d_Q, a->d_X, nullptr);
+    return e;
+}
+
 // makes `st` wait for what has been enqueued on `other` so far
 static hipError_t acq_order_after(hipStream_t st, hipStream_t other)
 {
@@ -532,6 +544,7 @@ static hipError_t acq_flush_inverse(gc_acq* a, hipStream_t st)
             else
                 e = acq_flush_final(a, st);
         }
+    if (e == hipSuccess) e = acq_forward(a, st, 1);
     if (e == hipSuccess) e = acq_inverse(a, st, false, a->inv_accumulate);
     return e;
 }
@@ -574,31 +587,32 @@ static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hi
         }
     if (e == hipSuccess && (a->use_cfar || bt))
         e = acq_launch_input_power(st, dev_iq, (int)a->consumed, (int)N, a->d_power, a->d_tmp, a->n_sats, N);
-    // the input block, zero padded to fft_size (:680-688), row-permuted once
-    if (e == hipSuccess) e = acq_launch_permute(st, dev_iq, nullptr, a->d_xw, a->plan, (int)a->consumed, 1, 0, 0, 0);
-    // x * wipeoff[d] (:717) fused into the load of the forward FFT per bin (:721), which every satellite shares
-    if (e == hipSuccess)
-        e = acq_launch_rows(st, false, a->plan, n_bins, a->d_wipe, AcqCellMap{1, n_bins}, a->d_xw, AcqCellMap{n_bins, 1 << 30}, a->d_Q, a->d_wN2, a->d_wN);
-    float2* X = a->d_X + (pair ? (size_t)n_bins * N : 0);
-    if (e == hipSuccess) e = acq_launch_cols(st, false, ACQ_EPI_PERM, a->plan, n_bins, a->d_Q, X, nullptr);
+    // the input block, zero padded to fft_size (:680-688), row-permuted once: the caller's buffer is free when this has run.  The
+    // second block of a pair goes behind the first one's
+    if (e == hipSuccess) e = acq_launch_permute(st, dev_iq, nullptr, a->d_xw + (pair ? N : 0), a->plan, (int)a->consumed, 1, 0, 0, 0);
     if (e == hipSuccess)
         {
             const int q_cells = a->sats_per_batch * (int)a->n_bins_alloc;
             if (pair)
                 {
+                    // both blocks' forward transforms in one pair of launches, then both dwells' inverse passes
                     a->inv_pending = false;
-                    e = acq_inverse(a, st, true, a->inv_accumulate);
+                    e = acq_forward(a, st, 2);
+                    if (e == hipSuccess) e = acq_inverse(a, st, true, a->inv_accumulate);
                 }
-            else if (a->fuse_dwells && plain && a->dwell_counter < a->max_dwells && q_cells >= 2 * n_bins)
+            else if (a->fuse_dwells && plain && a->dwell_counter < a->max_dwells && q_cells >= 2 * n_bins && a->n_bins_alloc >= 2)
                 {
-                    // more dwells of this search are expected: hold the inverse passes back (see gc_acq::inv_pending)
+                    // more dwells of this search are expected: hold everything behind the input permutation back (see gc_acq::inv_pending)
                     a->inv_pending = true;
                     a->inv_accumulate = accumulate;
                     a->inv_n_bins = n_bins;
                     a->inv_stream = st;
                 }
             else
-                e = acq_inverse(a, st, false, accumulate);
+                {
+                    e = acq_forward(a, st, 1);
+                    if (e == hipSuccess) e = acq_inverse(a, st, false, accumulate);
+                }
         }
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_dwell: kernel launch failed: %s", hipGetErrorString(e));
     a->grid_logically_zero = false;

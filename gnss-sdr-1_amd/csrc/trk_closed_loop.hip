@@ -23,6 +23,18 @@
 #include <vector>
 
 #define LOOP_MAX_CN0 64
+#ifndef LOOP_NT
+#define LOOP_NT 0  // nontemporal IQ loads: off -- the channels of a launch re-read one RF stream from the caches, period after period
+#endif
+#ifndef LOOP_WHOLE
+#define LOOP_WHOLE 0  // ragged first / last chunks fetched whole where they lie inside the buffer (trk_device.hpp): off -- a lone
+                      // workgroup per channel on cache-resident samples gains nothing from it and pays for the masks (0.713 vs 0.689 ms for
+                      // 256 channels x 64 periods)
+#endif
+#ifndef LOOP_ALIGN_PAIRS
+#define LOOP_ALIGN_PAIRS 1  // chunk grid of a window: the 16-byte one (the batched kernel's 128-byte grid makes nearly every period start with
+                            // a ragged chunk: 0.710 vs 0.689 ms)
+#endif
 #ifndef LOOP_PF
 #define LOOP_PF 2  // 16-byte loads in flight per lane; 4 was measured slower (0.72 vs 0.68 ms for 256 channels x 64 periods): a lone
                    // workgroup per CU is bound by instruction issue at two waves per SIMD, not by loads in flight
@@ -705,7 +717,7 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
             __syncthreads();
             if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
 
-            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA, LOOP_PF>(s.chan, s_p, 0, 1, lds_table_floats, lds);
+            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA, LOOP_PF, false, LOOP_NT != 0, LOOP_WHOLE != 0>(s.chan, s_p, 0, 1, lds_table_floats, lds, LOOP_ALIGN_PAIRS);
             if (tid < NTAPS + (DATA ? 1 : 0)) s_corr[tid] = r;
             __syncthreads();
 

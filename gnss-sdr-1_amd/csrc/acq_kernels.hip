@@ -1862,7 +1862,8 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             g.dbg = dbg;
             static const int persist = [] {
                 const char* e = std::getenv("GNSSCORR_ACQ_PERSIST");  // workgroups per CU of the persistent row launch (0: one block per group)
-                return e ? std::atoi(e) : 4;  // measured: 4 per CU (what the LDS admits) is 2 % faster than a block per group
+                return e ? std::atoi(e) : 0;  // measured: with the (bin, k1, sat) order 4 per CU (what the LDS admits) was 2 % faster than a block per group,
+                                              // with the (k1, bin, sat) order a block per group is 2-3 % faster (0.311-0.321 vs 0.320-0.327 ms per search)
             }();
             if (persist > 0 && entry->pair_fwd && fn == (inverse ? entry->pair_inv : entry->pair_fwd))
                 {

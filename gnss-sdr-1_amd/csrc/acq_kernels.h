@@ -68,6 +68,13 @@ hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const Acq
 
 int acq_cols_blocks(const AcqFftPlan& plan);
 
+// The inverse row pass of one batch (arguments as acq_launch_rows, inverse) and the two-dwell column pass (epilogue ACQ_EPI_MAG2 /
+// _MAG2_ACC, n_cells_cols grid cells read from Qc) of the previous batch in ONE launch; only for plans acq_rows_cols_fusable() accepts
+// (N = 25 x 1000, the planar pair row kernel)
+bool acq_rows_cols_fusable(const AcqFftPlan& plan);
+hipError_t acq_launch_rows_cols(hipStream_t st, const AcqFftPlan& plan, int n_cells, const float2* A, AcqCellMap mapA, const float2* B,
+    AcqCellMap mapB, float2* Q, const float2* wN2, const float2* wN, int epilogue, int n_cells_cols, const float2* Qc, const AcqMagArgs& mag);
+
 // phase[bin][n] = float32 running sum of phase_inc[bin] (volk_gnsssdr_s32f_sincos_32fc); out = (cos, sin)
 hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float2* out, int n_bins, int N);
 

@@ -816,24 +816,24 @@ static __device__ __forceinline__ void pk_powers10(VC<V> w, VC<V>* tw)
 #ifndef ACQ_ROWS3_WAVES
 #define ACQ_ROWS3_WAVES 4
 #endif
+// slot `slot` of `slots_per_xcd` on XCD `xcd` (the launch decides which blocks those are)
 template <bool INV>
-__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
+static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, const AcqRows2Args& g, float2* sm, int xcd, int slot, int slots_per_xcd)
 {
     constexpr int R = 10, N2 = 1000, NB = N2 / R, NP = NB / 2;
-    extern __shared__ float2 sm[];
     float* pre = reinterpret_cast<float*>(sm);  // plane of real parts: rpw rows of N2
     float* pim = pre + g.rpw * N2;              // plane of imaginary parts
     // Each XCD owns one contiguous eighth of the row groups (blocks with equal blockIdx % 8 share an L2); a workgroup walks its
     // XCD's groups with the stride of the launch: once when the grid has a block per group, several times when the launch is
     // sized to the chip (persistent form: the stores of one group drain behind the loads of the next instead of at the wave's end)
-    const int wg_per_xcd = gridDim.x >> 3;
+    const int wg_per_xcd = slots_per_xcd;
     const int groups_per_xcd = (g.n_groups + 7) >> 3;
     const int N = plan.N, N1 = plan.N1;
     const int p = threadIdx.x;
 #pragma nounroll
-    for (int gi = blockIdx.x >> 3; gi < groups_per_xcd; gi += wg_per_xcd)
+    for (int gi = slot; gi < groups_per_xcd; gi += wg_per_xcd)
     {
-    const int group = (blockIdx.x & 7) * groups_per_xcd + gi;
+    const int group = xcd * groups_per_xcd + gi;
     if (group >= g.n_groups) break;
     const int row0 = group * g.rpw;
     const int nrow = min(g.rpw, g.n_rows - row0);
@@ -975,6 +975,13 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel
         }
     __syncthreads();  // stage 3 has read the planes: the next group's stage 1 may overwrite them
     }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
+{
+    extern __shared__ float2 sm[];
+    acq_rows3_body<INV>(plan, g, sm, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3);
 }
 
 // stage list: RI = R*16 + ITER per stage, run in order
@@ -1168,13 +1175,14 @@ static __device__ __forceinline__ MaxPair max_pair(MaxPair a, MaxPair b)
 #ifndef ACQ_COLS_PAIR_WAVES
 #define ACQ_COLS_PAIR_WAVES 3  // the two-dwell epilogue is held to the registers of the one-dwell kernel (168: three waves per SIMD)
 #endif
+// one 256-column block `xblk` (of n_xblk) of cell `cell`.  p1s: N1 x ACQ_THREADS floats of LDS (two-dwell epilogues only), svs: 2 x
+// ACQ_THREADS / 64 words of LDS; a caller that loops over blocks puts a __syncthreads() between them
 template <int N1, bool INV, int EPI>
-__global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || EPI == ACQ_EPI_MAG2_ACC) ? ACQ_COLS_PAIR_WAVES : ACQ_COLS_WAVES) : 1)) void acq_cols_kernel(AcqFftPlan plan, const float2* __restrict__ Q,
-    float2* __restrict__ out, AcqMagArgs mag)
+static __device__ __forceinline__ void acq_cols_body(const AcqFftPlan& plan, const float2* __restrict__ Q, float2* __restrict__ out, const AcqMagArgs& mag,
+    int xblk, int n_xblk, int cell, float* __restrict__ p1s, float* __restrict__ svs)
 {
     const int N2 = plan.N2, N = plan.N;
-    const int n2 = blockIdx.x * ACQ_THREADS + threadIdx.x;
-    const int cell = blockIdx.y;
+    const int n2 = xblk * ACQ_THREADS + threadIdx.x;
     const bool active = n2 < N2;
     float2 v0[N1], v1[N1];
     // ACQ_EPI_MAG2: the rows pass ran over 2 * n_bins "bins" per satellite, the second half being the next dwell's spectra
@@ -1200,11 +1208,10 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
     float2* res = RegFft<N1, 1, N1, INV>::result_in_first ? v0 : v1;
     // first dwell's magnitudes wait in LDS (N1 x 256 floats: 25 KB of the 160) while the second column is transformed: in
     // registers they cost the third wave per SIMD (208 instead of 168), and so do the second column's loads hoisted above the first transform
-    __shared__ float p1[PAIR ? N1 : 1][PAIR ? ACQ_THREADS : 1];
     if (PAIR)
         {
 #pragma unroll
-            for (int k = 0; k < N1; k++) p1[PAIR ? k : 0][PAIR ? threadIdx.x : 0] = res[k].x * res[k].x + res[k].y * res[k].y;
+            for (int k = 0; k < N1; k++) p1s[k * ACQ_THREADS + threadIdx.x] = res[k].x * res[k].x + res[k].y * res[k].y;
             __builtin_amdgcn_sched_barrier(0);
             const float2* q2 = q + (size_t)mag.n_bins * N;
 #pragma unroll
@@ -1271,7 +1278,7 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
                                     if (PAIR)
                                         {
                                             // dwell 1: grid (+)= p1; dwell 2: grid += p, in the order two separate passes add
-                                            const float first = p1[PAIR ? k : 0][PAIR ? threadIdx.x : 0];
+                                            const float first = p1s[k * ACQ_THREADS + threadIdx.x];
                                             val = (EPI == ACQ_EPI_MAG2_ACC ? prev[HAS_PREV ? k : 0] + first : first) + p;
                                             if (tmp) tmp[idx] = p;
                                         }
@@ -1298,8 +1305,8 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
                     o.i = __shfl_down(best.i, off, 64);
                     best = max_pair(best, o);
                 }
-            __shared__ float sv[ACQ_THREADS / 64];
-            __shared__ unsigned si[ACQ_THREADS / 64];
+            float* sv = svs;
+            unsigned* si = reinterpret_cast<unsigned*>(svs + ACQ_THREADS / 64);
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
             if (lane == 0)
                 {
@@ -1315,8 +1322,51 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
                             MaxPair c = {sv[w], si[w]};
                             b = max_pair(b, c);
                         }
-                    mag.blk_max_val[(size_t)cell * gridDim.x + blockIdx.x] = b.v;
-                    mag.blk_max_idx[(size_t)cell * gridDim.x + blockIdx.x] = b.i;
+                    mag.blk_max_val[(size_t)cell * n_xblk + xblk] = b.v;
+                    mag.blk_max_idx[(size_t)cell * n_xblk + xblk] = b.i;
+                }
+        }
+}
+
+
+template <int N1, bool INV, int EPI>
+__global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || EPI == ACQ_EPI_MAG2_ACC) ? ACQ_COLS_PAIR_WAVES : ACQ_COLS_WAVES) : 1)) void acq_cols_kernel(AcqFftPlan plan, const float2* __restrict__ Q,
+    float2* __restrict__ out, AcqMagArgs mag)
+{
+    constexpr bool PAIR = (EPI == ACQ_EPI_MAG2 || EPI == ACQ_EPI_MAG2_ACC);
+    // first dwell's magnitudes wait in LDS (N1 x 256 floats: 25 KB of the 160) while the second column is transformed
+    __shared__ float p1[PAIR ? N1 * ACQ_THREADS : 1];
+    __shared__ float sv[2 * (ACQ_THREADS / 64)];
+    acq_cols_body<N1, INV, EPI>(plan, Q, out, mag, blockIdx.x, gridDim.x, blockIdx.y, p1, sv);
+}
+
+// Inverse row pass of one satellite batch and the two-dwell column pass of the PREVIOUS batch in one launch sized to the chip
+// (4 workgroups per CU): three of every four workgroups of an XCD walk the row groups, the fourth walks the column blocks.  The
+// row pass is bound by instruction issue and the LDS pipe and loses nothing with three workgroups per CU instead of four; the
+// column pass is bound by bandwidth the row pass leaves unused.  No dependency inside the launch: the columns read the buffer the
+// previous launch wrote, the rows write the other one.
+#ifndef ACQ_ROLE_COLS
+#define ACQ_ROLE_COLS 1
+#endif
+template <int EPI>
+__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_cols_kernel(AcqFftPlan plan, AcqRows2Args g, const float2* __restrict__ Qc,
+    AcqMagArgs mag, int n_cells_c, int n_xblk)
+{
+    extern __shared__ float2 sm[];
+    const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;  // per_xcd is a multiple of 4
+    constexpr int CS = ACQ_ROLE_COLS;  // column workgroups of every four
+    if ((s & 3) < 4 - CS)
+        acq_rows3_body<true>(plan, g, sm, xcd, (s >> 2) * (4 - CS) + (s & 3), per_xcd / 4 * (4 - CS));
+    else
+        {
+            float* lds = reinterpret_cast<float*>(sm);
+            const int cw_xcd = per_xcd / 4 * CS, n_cw = 8 * cw_xcd, items = n_cells_c * n_xblk;
+#pragma nounroll
+            for (int it = xcd * cw_xcd + (s >> 2) * CS + ((s & 3) - (4 - CS)); it < items; it += n_cw)
+                {
+                    const int cell = it / n_xblk;
+                    acq_cols_body<25, true, EPI>(plan, Qc, nullptr, mag, it - cell * n_xblk, n_xblk, cell, lds, lds + 25 * ACQ_THREADS);
+                    __syncthreads();
                 }
         }
 }
@@ -1795,6 +1845,52 @@ hipError_t acq_launch_permute(hipStream_t st, const float2* in, const float2* mu
     return hipGetLastError();
 }
 
+static int acq_rows_order()
+{
+    static const int row_order = [] {
+        const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");
+        return e ? std::atoi(e) : 2;
+    }();
+    return row_order;
+}
+
+bool acq_rows_cols_fusable(const AcqFftPlan& plan)
+{
+    int rpw, iters[ACQ_MAX_FACTORS];
+    return plan.N1 == 25 && plan.N2 == 1000 && plan.n_fac == 3 && plan.fac[0] == 10 && plan.fac[1] == 10 && plan.fac[2] == 10 &&
+           acq_rows2_config(plan, &rpw, iters) && (size_t)rpw * plan.N2 * sizeof(float2) >= (size_t)(25 * ACQ_THREADS + 2 * (ACQ_THREADS / 64)) * sizeof(float);
+}
+
+hipError_t acq_launch_rows_cols(hipStream_t st, const AcqFftPlan& plan, int n_cells, const float2* A, AcqCellMap mapA, const float2* B,
+    AcqCellMap mapB, float2* Q, const float2* wN2, const float2* wN, int epilogue, int n_cells_cols, const float2* Qc, const AcqMagArgs& mag)
+{
+    if (!acq_rows_cols_fusable(plan) || (epilogue != ACQ_EPI_MAG2 && epilogue != ACQ_EPI_MAG2_ACC)) return hipErrorInvalidValue;
+    AcqRows2Args g;
+    std::memset(&g, 0, sizeof g);
+    int iters[ACQ_MAX_FACTORS];
+    acq_rows2_config(plan, &g.rpw, iters);
+    g.A = A;
+    g.mapA = mapA;
+    g.B = B;
+    g.mapB = mapB;
+    g.Q = Q;
+    g.wN2 = wN2;
+    g.wN = wN;
+    g.n_rows = plan.N1 * n_cells;
+    g.n_bins = mapA.mod;
+    g.n_sats = n_cells / mapA.mod;
+    g.n_groups = (g.n_rows + g.rpw - 1) / g.rpw;
+    g.sat_fastest = g.n_sats > 1 ? acq_rows_order() : 0;
+    const size_t lds2 = (size_t)g.rpw * plan.N2 * sizeof(float2);
+    const int n_xblk = acq_cols_blocks(plan);
+    dim3 grid(256 * 4);  // 4 workgroups per CU (what the row pass's LDS admits), a multiple of 32
+    if (epilogue == ACQ_EPI_MAG2)
+        hipLaunchKernelGGL(acq_rows3_cols_kernel<ACQ_EPI_MAG2>, grid, dim3(ACQ_THREADS), lds2, st, plan, g, Qc, mag, n_cells_cols, n_xblk);
+    else
+        hipLaunchKernelGGL(acq_rows3_cols_kernel<ACQ_EPI_MAG2_ACC>, grid, dim3(ACQ_THREADS), lds2, st, plan, g, Qc, mag, n_cells_cols, n_xblk);
+    return hipGetLastError();
+}
+
 hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan, int n_cells,
     const float2* A, AcqCellMap mapA, const float2* B, AcqCellMap mapB,
     float2* Q, const float2* wN2, const float2* wN)
@@ -1850,11 +1946,7 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             // row order of the pair kernel: 0 = (bin, sat, k1), 1 = (bin, k1, sat), 2 = (k1, bin, sat) with the last digit running fastest.
             // An XCD walks a contiguous eighth of the rows; with 2 it needs row k1 of every spectrum and of every code at a time (a few
             // hundred KB, read once per launch), with 0 / 1 it sweeps all the codes once per bin and its L2 (4 MB) has dropped them by then.
-            static const int row_order = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");
-                return e ? std::atoi(e) : 2;
-            }();
-            g.sat_fastest = (B != nullptr && g.n_sats > 1) ? row_order : 0;
+            g.sat_fastest = (B != nullptr && g.n_sats > 1) ? acq_rows_order() : 0;
             static const int dbg = [] {
                 const char* e = std::getenv("GNSSCORR_ACQ_DBG");  // phase-elimination timing (ACQ_ROWS3_DBG builds only)
                 return e ? std::atoi(e) : 0;

@@ -78,6 +78,12 @@ struct gc_acq
     // d_Q double-buffered, events both ways.  Measured 0.42 instead of 0.355 ms per search: the row pass holds all the LDS of every CU
     // (4 x 40 KB), so the column workgroups do not become resident beside it and the eight cross-queue hand-overs only add latency
     bool overlap = false;
+    // Experiment, off by default ($GNSSCORR_ACQ_ROLES=1): with more than one satellite batch of dwell pairs, the row pass of batch b and
+    // the column pass of batch b - 1 share ONE launch (acq_rows3_cols_kernel: of every four workgroups of a CU, 4 - ACQ_ROLE_COLS do rows
+    // and ACQ_ROLE_COLS columns), d_Q double-buffered, no events.  Measured 0.44 (one column workgroup of four) and 0.33 (two) against
+    // 0.31 ms per search: a column workgroup needs its CU-mates' loads in flight to hide its two load phases, and the row pass slows down
+    // with fewer than three workgroups
+    bool roles = false;
     hipStream_t side = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
     size_t q_stride = 0;      // float2 elements between the two halves of d_Q (0: single buffer)
@@ -253,6 +259,9 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     ACQ_TRY(hipMalloc(&a->d_X, (size_t)2 * a->n_bins_alloc * N * sizeof(float2)));  // two dwells' spectra (see inv_pending)
     if (const char* e = std::getenv("GNSSCORR_ACQ_FUSE")) a->fuse_dwells = std::atoi(e) != 0;
     if (const char* e = std::getenv("GNSSCORR_ACQ_OVERLAP")) a->overlap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("GNSSCORR_ACQ_ROLES")) a->roles = std::atoi(e) != 0;
+    a->roles = a->roles && a->fuse_dwells && acq_rows_cols_fusable(a->plan);
+    if (a->roles && n_sats > 1) a->q_stride = q_cells * N;  // second inter-pass buffer
     if (a->overlap && a->sats_per_batch < n_sats)
         {
             // more than one batch: a second buffer, so that the rows of batch b + 1 run beside the columns of batch b
@@ -448,7 +457,46 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
         per_batch = (a->n_sats + n_batches - 1) / n_batches;  // equal batches
     }
     hipError_t e = hipSuccess;
-    const bool two_streams = a->q_stride != 0 && per_batch < a->n_sats;
+    auto mag_args = [&](int s0) {
+        AcqMagArgs m;
+        m.grid = a->d_grid + (size_t)s0 * n_bins * N;
+        m.tmp = a->d_tmp + (size_t)s0 * N;
+        m.blk_max_val = a->d_blkv + (size_t)s0 * n_bins * a->n_blocks;
+        m.blk_max_idx = a->d_blki + (size_t)s0 * n_bins * a->n_blocks;
+        m.offset = bt ? (int)a->eff : 0;
+        m.eff = (int)a->eff;
+        m.n_bins = n_bins;
+        m.tmp_bin = n_bins - 1;
+        return m;
+    };
+    if (pair && a->roles && a->q_stride != 0 && per_batch < a->n_sats && !a->overlap)
+        {
+            // rows(0); rows(b) + columns(b - 1) in one launch, b = 1 ..; columns(last)
+            const int epi = accumulate ? ACQ_EPI_MAG2_ACC : ACQ_EPI_MAG2;
+            int b = 0, prev_s0 = 0, prev_ns = 0;
+            for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += per_batch, b++)
+                {
+                    const int ns = std::min(per_batch, a->n_sats - s0);
+                    float2* Q = a->d_Q + (size_t)(b & 1) * a->q_stride;
+                    if (b == 0)
+                        e = acq_launch_rows(st, true, a->plan, ns * spectra, a->d_X, AcqCellMap{1, spectra}, a->d_codes + (size_t)s0 * N,
+                            AcqCellMap{spectra, 1 << 30}, Q, a->d_wN2, a->d_wN);
+                    else
+                        e = acq_launch_rows_cols(st, a->plan, ns * spectra, a->d_X, AcqCellMap{1, spectra}, a->d_codes + (size_t)s0 * N,
+                            AcqCellMap{spectra, 1 << 30}, Q, a->d_wN2, a->d_wN, epi, prev_ns * n_bins, a->d_Q + (size_t)((b - 1) & 1) * a->q_stride,
+                            mag_args(prev_s0));
+                    prev_s0 = s0;
+                    prev_ns = ns;
+                }
+            if (e == hipSuccess)
+                {
+                    const AcqMagArgs m = mag_args(prev_s0);
+                    e = acq_launch_cols(st, true, epi, a->plan, prev_ns * n_bins, a->d_Q + (size_t)((b - 1) & 1) * a->q_stride, nullptr, &m);
+                }
+        }
+    else
+    {
+    const bool two_streams = a->overlap && a->q_stride != 0 && per_batch < a->n_sats;
     int b = 0;
     for (int s0 = 0; s0 < a->n_sats && e == hipSuccess; s0 += per_batch, b++)
         {
@@ -476,6 +524,7 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
         }
     // everything behind this call on `st` sees the finished grid (the side stream runs its column passes in order: the last one's event covers all)
     if (e == hipSuccess && two_streams && b > 0) e = hipStreamWaitEvent(st, a->ev_cols[(b - 1) & 1], 0);
+    }
     if (e == hipSuccess)
         {
             AcqFinalArgs f;

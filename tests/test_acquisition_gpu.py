@@ -524,6 +524,44 @@ def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwe
         e.close()
 
 
+def test_row_and_column_roles_in_one_launch(gctx, oracle, monkeypatch):
+    """GNSSCORR_ACQ_ROLES=1 (an experiment that measured slower and is off by default): the row pass of a
+    satellite batch and the two-dwell column pass of the previous batch as roles of one launch, two inter-pass buffers.  N = 25000
+    (the only plan it exists for), 6 satellites in 3 batches of pairs: grids and results must equal the separate launches' bit for bit."""
+    import gnsscorr
+    import torch
+    from helpers import synth_stream
+    fs, n = 25_000_000, 25000
+    prns = [1, 4, 9, 17, 22, 30]
+    chips = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in prns[:3]]
+    x, _ = synth_stream(chips, fs, 2 * n, seed=1234, cn0_db_hz=(44.0, 48.0), doppler_max=800.0)
+    c = _conf(fs, 1, 1, 25000.0, 1000, 250, max_dwells=2)  # 8 bins
+    monkeypatch.setenv("GNSSCORR_ACQ_Q_MB", "8")  # 8 bins x 200 KB = 1.6 MB per satellite and dwell: 2 satellites of a pair per batch
+    eng = []
+    for roles in ("1", "0"):
+        monkeypatch.setenv("GNSSCORR_ACQ_ROLES", roles)
+        a = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
+        for s_, prn in enumerate(prns):
+            a.set_local_code(s_, oracle.gps_l1_ca_code_sampled(prn, fs))
+        eng.append(a)
+    d_x = torch.from_numpy(x.view(np.float32)).cuda()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    out = []
+    for a in eng:
+        a.reset()
+        a.dwell_enqueue(d_x.data_ptr(), st.cuda_stream)
+        a.dwell_enqueue(d_x.data_ptr() + 8 * n, st.cuda_stream)
+        out.append(a.fetch_results(st.cuda_stream))
+    for s_ in range(len(prns)):
+        assert np.array_equal(eng[0].grid(s_), eng[1].grid(s_)), s_
+        r1, r0 = out[0][s_], out[1][s_]
+        assert (r1.indext, r1.doppler_hz, r1.mag, r1.test_statistics, r1.second_peak) == (r0.indext, r0.doppler_hz, r0.mag, r0.test_statistics, r0.second_peak)
+    assert min(r.test_statistics for r in out[0][:3]) > max(r.test_statistics for r in out[0][3:])
+    for a in eng:
+        a.close()
+
+
 def test_gpu_grid_against_the_reference_matlab_analysis(gctx, oracle):
     """The same reference-held figures (plot_acq_grid_gsoc.m on the GSoC 2012 capture: PRN 11 10.8538 dB, PRN 12 9.3968 dB of peak
     over noise floor; tests/test_oracle_golden.py has the details) from the GPU's own grid, with the engine's own E1C replica."""

@@ -79,6 +79,62 @@ def test_batch_matches_oracle_many_channels(gctx, oracle):
     assert worst <= TOL, worst
 
 
+@pytest.mark.parametrize("fmt", ["f32", "i16", "i8"])
+def test_samples_next_to_a_window_never_enter_it(gctx, oracle, fmt):
+    """The batched kernel fetches the ragged first / last chunk of a window like the interior ones -- whole 16-byte pieces, up to 15
+    samples before the window and up to a chunk behind it, wherever those lie inside the channel's buffer -- and drops them in
+    registers (trk_device.hpp, mask_window).  Here every sample outside the windows is poison (NaN / +-Inf for float input, full
+    scale for the integer formats): windows at the very start of the buffer, at its very end, odd offsets, lengths that end anywhere
+    in a chunk, one and several slices.  Any leak shows as a NaN or as an error far beyond the tolerance."""
+    import gnsscorr
+    import torch
+    fs = 25_000_000
+    code = oracle.gps_l1_ca_code(11).astype(np.float32)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    rng = np.random.Generator(np.random.PCG64(4711))
+    lengths = [25000, 24576, 513, 511, 1, 7000, 12345]
+    gap = 40
+    starts, pos = [], 0  # the first window starts at sample 0, the last one ends with the buffer
+    for n in lengths:
+        starts.append(pos)
+        pos += n + gap + int(rng.integers(0, 9))
+    total = starts[-1] + lengths[-1]
+    sig, truth = synth_stream([code], fs, total, seed=77, cn0_db_hz=(50.0, 50.0))
+    inside = np.zeros(total, bool)
+    for s0, n in zip(starts, lengths):
+        inside[s0:s0 + n] = True
+    if fmt == "f32":
+        raw = sig.copy()
+        poison = np.array([np.nan + 1j * np.inf, -np.inf + 1j * np.nan, np.nan + 1j * np.nan], np.complex64)
+        raw[~inside] = poison[np.arange((~inside).sum()) % 3]
+        dev, iq_fmt, clean = torch.from_numpy(raw.view(np.float32)).cuda(), gnsscorr.GC_IQ_F32, sig
+    else:
+        scale, lim, dt = (300.0, 32767, np.int16) if fmt == "i16" else (25.0, 127, np.int8)
+        q = np.clip(np.round(sig.view(np.float32).reshape(-1, 2) * scale), -lim, lim).astype(dt)
+        clean = (q[:, 0].astype(np.float32) + 1j * q[:, 1].astype(np.float32)).astype(np.complex64)
+        q[~inside] = [lim, -lim]
+        dev, iq_fmt = torch.from_numpy(q).cuda(), (gnsscorr.GC_IQ_I16 if fmt == "i16" else gnsscorr.GC_IQ_I8)
+    recs, refs = [], []
+    for s0, n in zip(starts, lengths):
+        a = (float(np.float32(rng.uniform(0, 6))), float(np.float32(rng.uniform(-0.01, 0.01))), float(np.float32(rng.uniform(-400, 400))),
+            float(np.float32(1.023e6 / fs)))
+        recs.append(gnsscorr.epoch_params(s0, a[0], a[1], a[2], a[3], n))
+        refs.append(oracle.multicorrelator(clean[s0:], code, shifts, np.float32(a[0]), np.float32(a[1]), np.float32(a[2]), np.float32(a[3]), n))
+    for slices in (1, 3):
+        b = gnsscorr.TrackingBatch(gctx, 1, 3, 1023)
+        if iq_fmt != gnsscorr.GC_IQ_F32:
+            b.set_input_format(iq_fmt)
+        b.set_code(0, code, shifts)
+        b.set_input_dev(0, dev.data_ptr(), total)
+        b.set_slices(slices)
+        got = b.run(len(recs), gnsscorr.epoch_params_array([recs]))[0]
+        b.close()
+        assert np.all(np.isfinite(got.view(np.float32))), (fmt, slices)
+        for k, ref in enumerate(refs):
+            tol = 1e-4 * float(np.max(np.abs(ref))) + 6e-5 * np.sqrt(lengths[k]) * float(np.max(np.abs(clean)))
+            assert float(np.max(np.abs(got[k] - ref))) <= tol, (fmt, slices, k, got[k], ref)
+
+
 def test_sliced_epochs_equal_unsliced(gctx, oracle):
     """Cutting an epoch into slices only changes the summation order."""
     import gnsscorr

@@ -510,15 +510,7 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
             if (e == hipSuccess && two_streams) e = hipEventRecord(a->ev_rows[b & 1], st);
             if (e == hipSuccess && two_streams) e = hipStreamWaitEvent(cst, a->ev_rows[b & 1], 0);
             if (e != hipSuccess) break;
-            AcqMagArgs m;
-            m.grid = a->d_grid + (size_t)s0 * n_bins * N;
-            m.tmp = a->d_tmp + (size_t)s0 * N;
-            m.blk_max_val = a->d_blkv + (size_t)s0 * n_bins * a->n_blocks;
-            m.blk_max_idx = a->d_blki + (size_t)s0 * n_bins * a->n_blocks;
-            m.offset = bt ? (int)a->eff : 0;
-            m.eff = (int)a->eff;
-            m.n_bins = n_bins;
-            m.tmp_bin = n_bins - 1;
+            const AcqMagArgs m = mag_args(s0);
             e = acq_launch_cols(cst, true, pair ? (accumulate ? ACQ_EPI_MAG2_ACC : ACQ_EPI_MAG2) : (accumulate ? ACQ_EPI_MAG_ACC : ACQ_EPI_MAG), a->plan, ns * n_bins, Q, nullptr, &m);
             if (e == hipSuccess && two_streams) e = hipEventRecord(a->ev_cols[b & 1], cst);
         }

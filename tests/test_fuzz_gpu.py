@@ -136,6 +136,18 @@ def test_randomised_acquisition_parity(gctx, oracle):
                 assert r.mag == pytest.approx(q.mag, rel=1e-4) and r.test_statistics == pytest.approx(q.test_statistics, rel=2e-4), (c, s, d)
         grid, ref = acq.grid(0), orcs[0].grid()
         assert np.max(np.abs(grid - ref)) <= 1e-4 * ref.max(), c
+        if max_dwells > 1:
+            # the same search with its dwells enqueued back to back: they run in pairs (gc_acquisition.hip) -- not a bit may differ
+            import torch
+            d_x = torch.from_numpy(x.view(np.float32)).cuda()
+            torch.cuda.synchronize()
+            acq.reset()
+            for d in range(max_dwells):
+                acq.dwell_enqueue(d_x.data_ptr() + 8 * consumed * d, 0)
+            again = acq.fetch_results(0)
+            for s in range(n_sats):
+                assert (again[s].indext, again[s].doppler_hz, again[s].mag, again[s].test_statistics) == (res[s].indext, res[s].doppler_hz, res[s].mag, res[s].test_statistics), (c, s)
+            assert np.array_equal(acq.grid(0), grid), c
         acq.close()
         done += 1
     print("acquisition cases: %d checked, %d sizes refused" % (done, unsupported))

@@ -229,19 +229,22 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream around the WHOLE timed region: the kernel's average launch duration is their distance / K.  (A
+    # pair of events per step -- rounds 1 and 2a -- puts two event packets between consecutive launches: ~12 us of idle GPU per
+    # step, 0.262 instead of 0.250 ms, inside the wall-clock region as well.)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
-        ev[i][0].record()
         step()
-        ev[i][1].record()
+    ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
 
     samples_per_step = N_CHANNELS * E * N_EPOCH  # per GPU
     value = sharding.aggregate_throughput(samples_per_step, args.steps, world, elapsed) / 1e6
@@ -510,13 +513,13 @@ def main():
             acq_search()
             torch.cuda.synchronize()
             reps = args.acq_reps
-            aev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-            for a0, a1 in aev:
-                a0.record()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()  # one pair of events around all the searches (a pair per search idles the GPU ~12 us between searches)
+            for _ in range(reps):
                 acq_search()
-                a1.record()
+            a1.record()
             torch.cuda.synchronize()
-            acq_ms = float(np.mean([a0.elapsed_time(a1) for a0, a1 in aev]))
+            acq_ms = float(a0.elapsed_time(a1)) / reps
             # sanity: stream 0 carries PRN 1 only -- it must win, at its code phase and in its Doppler bin
             ares = acq.fetch_results(stream)
             stats = np.array([r.test_statistics for r in ares])

@@ -140,5 +140,30 @@ int main(int argc, char** argv)
     run<2, 6, false, 3, true>("pf2 + 24 fma + 3 lookups + prologue", d, o, n_win, n_pairs);
     run<2, 6, true, 3, true>("the same, nt", d, o, n_win, n_pairs);
     run<2, 6, true, 5, true>("pf2 + 24 fma + 5 lookups + prologue, nt", d, o, n_win, n_pairs);
+    {
+        // a long back-to-back run of the model closest to the tracking kernel, launch by launch: does it slow down as the real one does
+        // (242 us for the first ten launches, 262-289 us some 3 ms into a run)?
+        static float* table = nullptr;
+        hipMalloc(&table, 4096);
+        hipMemset(table, 0, 4096);
+        const int reps = 60;
+        hipEvent_t ev[reps + 1];
+        for (int r = 0; r <= reps; r++) hipEventCreate(&ev[r]);
+        hipEventRecord(ev[0]);
+        for (int r = 0; r < reps; r++)
+            {
+                hipLaunchKernelGGL((sweep<2, 10, true, 3, true>), dim3(n_win), dim3(256), 0, 0, d, o, n_pairs, table, 0.0409f);
+                hipEventRecord(ev[r + 1]);
+            }
+        hipEventSynchronize(ev[reps]);
+        printf("pf2 + 40 fma + 3 lookups + prologue, nt, 60 launches back to back (us):");
+        for (int r = 0; r < reps; r++)
+            {
+                float ms = 0;
+                hipEventElapsedTime(&ms, ev[r], ev[r + 1]);
+                printf(" %.0f", ms * 1e3);
+            }
+        printf("\n");
+    }
     return 0;
 }

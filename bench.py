@@ -38,6 +38,8 @@ N_CHANNELS = 32          # per GPU
 N_TAPS = 3
 CODE_LEN = 1023
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# <NTAPS, HDR, HDC, FMT = GC_IQ_F32, CC, SC16>: the name rocprofv3 prints for the headline kernel
+TRK_KERNEL_NAME = "trk_multicorrelator_kernel<3, false, false, 0, false, false, false>"
 
 
 def gps_ca_code(prn):
@@ -151,8 +153,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-acq", action="store_true")
     ap.add_argument("--acq-reps", type=int, default=5, help="timed acquisition searches (profiles/collect.sh counts on this)")
+    ap.add_argument("--acq-warmup", type=int, default=20, help="untimed acquisition searches in front of the timed ones (named in the JSON)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-shared", action="store_true", help="skip the shared-stream extra (clean rocprof runs)")
+    ap.add_argument("--segments", type=int, default=24, help="untimed diagnostic pass behind the timed region: this many segments of "
+        "5 back-to-back launches, one HIP event between segments (0: skip)")
+    ap.add_argument("--preroll-ms", type=float, default=15.0, help="untimed launches of the same step IN FRONT of the W warm-up steps, "
+        "about this many ms of GPU time (named in the JSON line as `preroll`; 0: none, the timed region then starts W steps after idle)")
     args = ap.parse_args()
 
     import torch
@@ -226,6 +233,15 @@ def main():
         torch.cuda.synchronize()
 
     torch.cuda.synchronize()  # inputs were generated on the default stream
+    # Pre-roll (NAMED in the JSON line: `preroll`): a receiver tracks continuously, a 20-step timed region is 5 ms.  On this chip the
+    # first ~8 ms of load after an idle period are a power-management transient (launches at 240-245 us for 3 ms, then 260-300 us
+    # for 5 ms, then the steady 245-250 us; profiles/r03_tracking_kernel_trace.csv), and W = 5 warm-up steps end 1.3 ms into it.
+    # The pre-roll runs the SAME step untimed until the transient is over, then the W warm-up steps and the barrier follow as the
+    # contract says; the timed region itself is untouched (K full steps, nothing skipped).  --preroll-ms 0 gives the cold-start
+    # figure, which the diagnostic pass below reports as well (`cold_start_kernel_ms`).
+    n_preroll = int(round(args.preroll_ms / 0.25)) if args.preroll_ms > 0 else 0
+    for _ in range(n_preroll):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -239,17 +255,55 @@ def main():
         step()
     ev1.record()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed_local, dist, red_dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
 
+    # ---- diagnostic pass, OUTSIDE the timed region and after it (it changes neither `value` nor `ms_per_step` nor `kernel_ms`):
+    # the same lead-in as the timed region (W warm-up launches from an idle GPU, synchronise), then SEG_LEN x n_seg back-to-back
+    # launches with ONE event between segments.  The first ceil(K / SEG_LEN) segments re-enact the timed region; the later ones
+    # show where the launch time settles (`steady_state_kernel_ms` = median of the second half) -- so the line itself says
+    # whether the timed region sat in the start-of-load transient of the box it ran on.
+    SEG_LEN = 5
+    COLD_IDLE_S = 0.25
+    segments_ms, steady_ms, cold_ms = None, None, None
+    if args.segments > 0:
+        torch.cuda.synchronize()
+        time.sleep(COLD_IDLE_S)  # let the chip fall back to its idle power state: this pass starts cold, with NO pre-roll
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.segments + 1)]
+        evs[0].record()
+        for sgi in range(args.segments):
+            for _ in range(SEG_LEN):
+                step()
+            evs[sgi + 1].record()
+        torch.cuda.synchronize()
+        segments_ms = [float(evs[i].elapsed_time(evs[i + 1])) / SEG_LEN for i in range(args.segments)]
+        tail = sorted(segments_ms[args.segments // 2:])
+        steady_ms = tail[len(tail) // 2]
+        # what the timed region would have measured without the pre-roll: the first K launches of this cold pass
+        n_cold = min(args.segments, max(1, -(-args.steps // SEG_LEN)))
+        cold_ms = sum(segments_ms[:n_cold]) / n_cold
+
     samples_per_step = N_CHANNELS * E * N_EPOCH  # per GPU
     value = sharding.aggregate_throughput(samples_per_step, args.steps, world, elapsed) / 1e6
     alg_bytes = 8.0 * samples_per_step
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    # per-GPU figures (north_star: "per-GPU Msamples/s and achieved HBM-bandwidth fraction at 1/2/4/8 GPUs"): every rank's own
+    # wall time over the timed steps and its own kernel time, gathered on all ranks; rank 0 prints them
+    mine = {"rank": rank, "device": dev_index, "elapsed_s": elapsed_local, "kernel_ms": kernel_ms,
+        "msamples_s": samples_per_step * args.steps / elapsed_local / 1e6,
+        "hbm_frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "steady_state_kernel_ms": steady_ms,
+        "steady_state_hbm_frac": (alg_bytes / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if steady_ms else None,
+        "cold_start_kernel_ms": cold_ms}
+    per_gpu = sharding.gather_per_rank(mine, dist, world)
 
     # sanity: the prompt correlators see their signals (guards against timing a broken path)
     out = d_out.cpu().numpy().reshape(N_CHANNELS, E, N_TAPS, 2)
@@ -510,7 +564,11 @@ def main():
                 acq.reset()
                 acq.dwell_enqueue(x.data_ptr(), stream)
                 acq.dwell_enqueue(x.data_ptr() + 8 * N_EPOCH, stream)
-            acq_search()
+                acq.flush(stream)  # this search's own statistics kernel, enqueued behind its passes (no host synchronisation)
+            # untimed warm-up searches (named in the JSON: `warmup_searches`): ~6 ms of the same load, so that the timed searches
+            # lie behind the start-of-load power transient like the tracking steps do
+            for _ in range(max(1, args.acq_warmup)):
+                acq_search()
             torch.cuda.synchronize()
             reps = args.acq_reps
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -535,8 +593,8 @@ def main():
             acq_gbps = acq_alg / (acq_ms * 1e-3) / 1e9
             aroof = {"bound": "hbm", "achieved": acq_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": acq_gbps / HBM_PEAK_GBPS,
                 "algorithmic_bytes_per_search": acq_alg, "search_ms": acq_ms,
-                "note": "whole search (2 dwells: shared forward transforms, inverse row + column passes of every cell, statistics) timed with "
-                        "HIP events on the launch stream; achieved = algorithmic bytes / that time", "traffic": None}
+                "note": "whole search (2 dwells: shared forward transforms, inverse row + column passes of every cell, its own statistics "
+                        "kernel via gc_acq_flush) timed with HIP events on the launch stream; achieved = algorithmic bytes / that time", "traffic": None}
             apath = os.path.join(ROOT, "profiles", "acq_latest.json")
             if os.path.exists(apath):
                 try:
@@ -548,11 +606,12 @@ def main():
                 except Exception:
                     pass
             extra["acquisition"] = {"dwells_per_s": n_sat * n_dw / (acq_ms * 1e-3), "ms_per_search": acq_ms,
+                "timed_searches": reps, "warmup_searches": max(1, args.acq_warmup),
                 "workload": "GPS L1 C/A PCPS, 25 Msps, N=25000, 32 PRNs x 41 Doppler bins x 2 dwells", "roofline": aroof}
             if not args.no_cpu and world == 1:
                 # CPU baseline of the same search: the oracle's acquisition_core restatement (own float64 mixed-radix FFT, gcc -O3
                 # -march=native, 1 thread) on a bounded sample: PRN-dwells of the same block sizes and Doppler grid
-                from oracle import Oracle
+                from oracle import Oracle, host_cpu_model
                 orc = Oracle(native=True)
                 xh = x[:2 * N_EPOCH].cpu().numpy().view(np.complex64).reshape(-1)
                 pc = orc.pcps(fs_in=FS, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(FS) * np.float32(0.001), samples_per_code=25000.0,
@@ -566,8 +625,9 @@ def main():
                         n_done += 1
                 dtc = time.perf_counter() - t0c
                 extra["acquisition"]["cpu_baseline"] = {"value": n_done / dtc, "unit": "dwells/s", "cores": 1, "kind": "port",
-                    "sample": "%d PRN-dwells (41 Doppler bins x N=25000 each, 2-dwell searches of PRN 1) in %.1f s, oracle PCPS "
-                              "(acquisition_core restatement with its own float64 FFT, gcc -O3 -march=native), 1 thread" % (n_done, dtc)}
+                    "sample": "%d PRN-dwells (41 Doppler bins x N=25000 each, 2-dwell searches of PRN 1) in %.1f s, oracle PCPS: float64 "
+                              "mixed-radix FFT port, NOT the reference's FFTW3f float32 path (pcps_acquisition.cc:721-727), so far slower than "
+                              "the real block; gcc -O3 -march=native built on this host (%s), 1 thread" % (n_done, dtc, host_cpu_model())}
             acq.close()
 
         cpu = None
@@ -585,9 +645,10 @@ def main():
                 carr = (t["phi"] + 2 * np.pi * t["doppler"] * start / FS) % (2 * np.pi)
                 recs.append((start, np.float32(carr), np.float32(2 * np.pi * t["doppler"] / FS), np.float32(rem), np.float32(step_c)))
             v, n_done, dt = cpu_baseline(codes[0], shifts, sig0, recs, args.cpu_seconds)
+            from oracle import host_cpu_model
             cpu = {"value": v, "unit": "Msamples/s", "cores": 1, "kind": "port",
                 "sample": "%d channel-epochs of the same workload (GPS L1 C/A, N=25000, 3 taps) in %.1f s, oracle "
-                          "(volk_gnsssdr generic restatement, gcc -O3 -march=native), 1 thread" % (n_done, dt)}
+                          "(volk_gnsssdr generic restatement, gcc -O3 -march=native built on this host: %s), 1 thread" % (n_done, dt, host_cpu_model())}
             # the same port with one thread per channel on every host core this process may use
             n_thr = max(1, min(len(os.sched_getaffinity(0)), N_CHANNELS))
             if n_thr > 1:
@@ -618,9 +679,27 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 # <NTAPS, HDR, HDC, FMT = GC_IQ_F32, CC, SC16>: the name rocprofv3 prints
-                "kernel": "trk_multicorrelator_kernel<3, false, false, 0, false, false, false>", "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_launch": alg_bytes},
+                "kernel": TRK_KERNEL_NAME, "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                # diagnostic pass behind the timed region (see above): per-launch ms of consecutive 5-launch segments of a COLD start
+                # (no pre-roll) with the same W-launch lead-in, and where they settle
+                "segments_ms": segments_ms, "segment_launches": SEG_LEN,
+                "steady_state_kernel_ms": steady_ms,
+                "steady_state_frac": (alg_bytes / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if steady_ms else None,
+                "cold_start_kernel_ms": cold_ms,
+                "cold_start_frac": (alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if cold_ms else None,
+                "segments_note": "untimed pass AFTER the timed region: GPU idle for %.2f s -> %d warm-up launches -> synchronise -> %d x %d "
+                                 "launches back to back, one HIP event per segment.  cold_start_* = mean of its first %d launches = what "
+                                 "the timed region measures with --preroll-ms 0; steady_state_* = median of its second half.  frac / "
+                                 "kernel_ms above are the timed region's (behind the named pre-roll)"
+                                 % (COLD_IDLE_S, args.warmup, args.segments, SEG_LEN, args.steps)},
+            "preroll": {"launches": n_preroll, "approx_ms": args.preroll_ms,
+                "note": "untimed launches of the same step in front of the W warm-up steps, so that the timed region lies behind the chip's "
+                        "start-of-load power transient (~8 ms); the timed region is unchanged: K full steps between barrier + synchronise. "
+                        "--preroll-ms 0 removes it; roofline.cold_start_frac is the figure without it"},
             "cpu_baseline": cpu,
+            "per_gpu": [{k: g[k] for k in ("rank", "msamples_s", "hbm_frac", "kernel_ms", "steady_state_kernel_ms", "steady_state_hbm_frac", "cold_start_kernel_ms")} for g in per_gpu],
+            "slowest_rank": max(per_gpu, key=lambda g: g["elapsed_s"])["rank"],
         }
         result.update(extra)
     if dist is not None:

@@ -695,6 +695,17 @@ gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* str
     return acq_fetch(a, host_results, gc_pick_stream(a->ctx, stream));
 }
 
+gc_status gc_acq_flush(gc_acq* a, void* stream)
+{
+    GC_REQUIRE(a, "gc_acq_flush: NULL handle");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = gc_pick_stream(a->ctx, stream);
+    GC_HIP(acq_flush_inverse(a, st));
+    GC_HIP(acq_flush_final(a, st));
+    return GC_OK;
+}
+
 gc_status gc_acq_dwell_dev(gc_acq* a, const void* dev_iq, gc_acq_result* host_results, void* stream)
 {
     GC_REQUIRE(a && dev_iq && host_results, "gc_acq_dwell_dev: NULL argument");

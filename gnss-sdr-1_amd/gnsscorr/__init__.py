@@ -242,6 +242,7 @@ API = {
     "gc_acq_dwell": (C.c_int, [_vp, _fp, C.POINTER(AcqResult)]),
     "gc_acq_dwell_enqueue": (C.c_int, [_vp, _vp, _vp]),
     "gc_acq_fetch_results": (C.c_int, [_vp, C.POINTER(AcqResult), _vp]),
+    "gc_acq_flush": (C.c_int, [_vp, _vp]),
     "gc_acq_get_grid": (C.c_int, [_vp, C.c_int, _fp]),
 }
 
@@ -850,6 +851,10 @@ class PcpsAcquisition:
 
     def dwell_enqueue(self, dev_ptr, stream=None):
         _check(load_library().gc_acq_dwell_enqueue(self._h, _vp(dev_ptr), _vp(stream or 0)))
+
+    def flush(self, stream=None):
+        """Enqueues held-back inverse passes and the last dwell's statistics kernel; no copy, no synchronisation."""
+        _check(load_library().gc_acq_flush(self._h, _vp(stream or 0)))
 
     def fetch_results(self, stream=None):
         res = (AcqResult * self.n_sats)()

@@ -35,6 +35,16 @@ def max_over_ranks(value, dist=None, device=None):
     return float(t.item())
 
 
+def gather_per_rank(record, dist=None, world=1):
+    """Every rank's small record (a dict of python scalars), in rank order, on every
+    rank: the per-GPU figures of the multi-GPU bench line.  Identity without a group."""
+    if dist is None or not dist.is_initialized():
+        return [record]
+    out = [None] * world
+    dist.all_gather_object(out, record)
+    return sorted(out, key=lambda r: r["rank"])
+
+
 def aggregate_throughput(units_per_rank_per_step, steps, world, elapsed_max_s):
     """Whole-job throughput: units all ranks processed / max-over-ranks time."""
     return units_per_rank_per_step * world * steps / elapsed_max_s

@@ -525,6 +525,11 @@ gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_resu
  * to per-dwell processing; $GNSSCORR_ACQ_FUSE=0 (read by gc_acq_create) turns the pairing off. */
 gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream);
 gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* stream);
+/* Enqueues on `stream` whatever the enqueue-only calls have held back -- the inverse passes of a dwell waiting for a partner
+ * and the statistics kernel of the last dwell (pcps_acquisition.cc:747-755 evaluates after every dwell) -- without copying
+ * anything to the host and without synchronising: afterwards the device-side results are those of the last dwell, in stream
+ * order.  gc_acq_fetch_results() = this + the copy + a stream synchronisation. */
+gc_status gc_acq_flush(gc_acq* a, void* stream);
 /* One dwell on the block of consumed_samples that starts at absolute sample first_index of the ring `s`
  * (the stream's format must equal gc_acq_set_input_format's; synchronous like gc_acq_dwell). */
 gc_status gc_acq_dwell_stream(gc_acq* a, gc_stream* s, uint64_t first_index, gc_acq_result* host_results);

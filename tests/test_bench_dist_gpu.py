@@ -28,3 +28,24 @@ def test_bench_under_torchrun_with_rccl_process_group():
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 0
     assert j["roofline"]["traffic"] is None  # another workload than the profiled one: no borrowed counter figure
+
+
+def test_two_ranks_report_per_gpu_figures():
+    """Two ranks (gloo, both on the one GPU of the box: BENCH_FORCE_DEVICE) through bench.py's N > 1 path: the line carries one
+    per_gpu entry per rank -- own Msamples/s, own kernel time and HBM fraction -- and names the slowest rank."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--epochs", "16", "--segments", "4", "--no-cpu"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and [g["rank"] for g in j["per_gpu"]] == [0, 1] and j["slowest_rank"] in (0, 1)
+    for g in j["per_gpu"]:
+        assert g["msamples_s"] > 0 and 0 < g["hbm_frac"] < 1 and g["kernel_ms"] > 0 and g["steady_state_kernel_ms"] > 0
+    # whole-job value = all ranks' units / the slowest rank's time: never above the sum of the per-GPU rates
+    assert j["value"] <= sum(g["msamples_s"] for g in j["per_gpu"]) * (1 + 1e-9)
+    assert len(j["roofline"]["segments_ms"]) == 4

@@ -327,3 +327,51 @@ def test_closed_loop_standby_slots_and_stop(gctx, oracle):
     with pytest.raises(gnsscorr.GnsscorrError, match="no channel has been started"):
         loop.run(1)
     loop.close()
+
+
+@pytest.mark.parametrize("order,fll_pull_in,fll_steady", [(3, 0, 0), (2, 0, 0), (3, 0, 1), (2, 1, 0), (3, 1, 0)])
+def test_device_carrier_filter_against_the_pinned_filter(gctx, oracle, order, fll_pull_in, fll_steady):
+    """The device loop's copy of Tracking_FLL_PLL_filter (trk_closed_loop.hip::pll_get_carrier_error) against
+    tests/closed_loop_ref.py::Pll, which tests/test_loop_filter_pin.py holds BIT FOR BIT to the reference's filter compiled in
+    oracle/_ref: the pinned filter is fed with the discriminator outputs the DEVICE recorded (carr_phase_error_hz is the
+    filter's own float input; the FLL discriminator is re-derived from the recorded prompt accumulators with the reference's
+    formula, tracking_discriminators.cc:41-56) and must reproduce the recorded carrier_doppler_hz -- exactly where only the PLL
+    input is used, within 2 float32 ulp where the re-derived FLL input (a double atan2 on another libm) enters."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import Pll
+    fs, n_ep = 4e6, 120
+    code, x = _signal(oracle, 9, fs, 4000 * (n_ep + 3), 303, -2210.0, 2345.0)
+    conf = dict(GPS, acq_delay_samples=2345.0, acq_doppler_hz=-2200.0, acq_samplestamp_samples=0, sample_counter=0,
+        pll_filter_order=order, enable_fll_pull_in=fll_pull_in, enable_fll_steady_state=fll_steady)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    assert np.all(rec["valid"] == 1) and np.all(rec["state"] == 2)
+    f = Pll(conf["fll_bw_hz"], conf["pll_bw_hz"], order)
+    f.initialize(np.float32(conf["acq_doppler_hz"]))
+    T = np.float32(conf["code_period_s"])
+    p_old = np.zeros(2, np.float32)
+    worst = 0
+    for k in range(n_ep):
+        g = rec[k]
+        P = np.array([g["accu"][4], g["accu"][5]], np.float32)  # the prompt accumulator the discriminators saw
+        pll_in = np.float32(g["carr_phase_error_hz"])
+        if fll_pull_in or fll_steady:
+            dot = np.float32(np.float32(p_old[0] * P[0]) + np.float32(p_old[1] * P[1]))
+            cross = np.float32(np.float32(p_old[0] * P[1]) - np.float32(P[0] * p_old[1]))
+            fll_in = np.float32(np.arctan2(float(cross), float(dot)) / conf["code_period_s"] / (2.0 * np.pi))  # double, like the device
+            p_old = P
+            want = f.get_carrier_error(fll_in, np.float32(0.0) if fll_pull_in else pll_in, T)
+        else:
+            want = f.get_carrier_error(np.float32(0.0), pll_in, T)
+        got = np.float32(g["carrier_doppler_hz"])
+        ulp = abs(int(np.float32(want).view(np.int32)) - int(got.view(np.int32)))
+        worst = max(worst, ulp)
+        if not (fll_pull_in or fll_steady):
+            assert ulp == 0, (k, float(want), float(got))
+        # keep the pinned filter on the device's trajectory: its state is a function of its inputs only, so nothing to re-seed
+    assert worst <= (2 if (fll_pull_in or fll_steady) else 0), worst

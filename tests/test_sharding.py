@@ -20,6 +20,7 @@ def test_shard_partition_properties():
         sharding.shard_channels(8, 2, 2)
     assert sharding.max_over_ranks(1.5) == 1.5
     assert sharding.aggregate_throughput(100.0, 10, 8, 2.0) == 4000.0
+    assert sharding.gather_per_rank({"rank": 0, "x": 1.0}) == [{"rank": 0, "x": 1.0}]
 
 
 def _worker(rank, world, port, q):
@@ -37,7 +38,9 @@ def _worker(rank, world, port, q):
     worst = sharding.max_over_ranks(elapsed, dist)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
-    q.put((rank, mine, worst, gathered))
+    # the per-GPU figures of the bench line: every rank's own record, in rank order, on every rank
+    per_gpu = sharding.gather_per_rank({"rank": rank, "elapsed_s": elapsed, "kernel_ms": 0.25 + 0.01 * rank}, dist, world)
+    q.put((rank, mine, worst, gathered, per_gpu))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +60,9 @@ def test_two_rank_gloo_sharding_and_max_time():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, m0, w0, g0), (r1, m1, w1, g1) = res
+    (r0, m0, w0, g0, p0), (r1, m1, w1, g1, p1) = res
     assert m0 == [0, 2, 4, 6] and m1 == [1, 3, 5, 7]
     assert w0 == w1 == pytest.approx(0.020)
     assert sorted(c for part in g0 for c in part) == list(range(8))
+    assert p0 == p1 and [g["rank"] for g in p0] == [0, 1]
+    assert p0[1]["kernel_ms"] == pytest.approx(0.26) and max(p0, key=lambda g: g["elapsed_s"])["rank"] == 1

@@ -611,13 +611,14 @@ static void test_level1_scales_with_channel_threads()
                 static_cast<unsigned long long>(b1 - b0), static_cast<unsigned long long>(r1 - r0), mb, static_cast<unsigned long long>(s1 - s0));
             EXPECT(bad.load() == 0, "%d calls failed", bad.load());
             EXPECT(r1 - r0 == static_cast<uint64_t>(n_threads) * calls, "batcher served %llu calls", static_cast<unsigned long long>(r1 - r0));
-            // The calls overlap: 64 threads finish in less than 64 x the single-thread latency / 8 on the flowgraph's topology, with
-            // or without the buffer registered (measured 8.8-10.3x and 9.9-11.8x; the gate of the unregistered form leaves a margin for
-            // a busy host); 8.3-9.8x when every thread hands in the same pointer; with a buffer per thread every call stages and moves
-            // its own 200 KB (4.6-4.8x).  Every thread sleeps and is woken once per call, 64 threads on
-            // the box's 16 cores: the gates leave room for the scheduler's mood.
-            const bool timing_gates = std::getenv("GNSSCORR_SELFTEST_NO_TIMING") == nullptr;  // sanitizer builds check values only
-            static const double gate[4] = {6.0, 7.0, 8.0, 3.0};  // measured 8.3-9.8, 8.8-10.3, 9.9-11.8, 4.6-4.8
+            // What is ASSERTED is the batching itself -- every call served, in fewer launches than calls -- and the values below.  The
+            // wall-clock ratio printed above is a MEASUREMENT (8.3-9.8x shared pointer, 8.8-10.3x flowgraph topology, 9.9-11.8x
+            // registered, 4.6-4.8x a buffer per thread on a quiet 16-core box): 64 threads sleep and wake once per call, so it
+            // follows the host scheduler's load, and a correctness suite must not.  GNSSCORR_SELFTEST_TIMING_GATES=1 turns the old
+            // x6 / x7 / x8 / x3 gates back on for a perf run.
+            EXPECT(b1 - b0 < r1 - r0, "no batching: %llu launches for %llu calls", static_cast<unsigned long long>(b1 - b0), static_cast<unsigned long long>(r1 - r0));
+            const bool timing_gates = std::getenv("GNSSCORR_SELFTEST_TIMING_GATES") != nullptr;
+            static const double gate[4] = {6.0, 7.0, 8.0, 3.0};
             EXPECT(!timing_gates || total_us < serial_us / gate[topo], "no overlap: %.0f us for %d x %d calls, %.1f us each alone", total_us, n_threads, calls, single_us);
             for (int t = 0; t < n_threads; t += 7)
                 {
@@ -629,6 +630,27 @@ static void test_level1_scales_with_channel_threads()
                 }
             if (topo == 2) EXPECT(gc_ctx_unregister_host_buffer(gnsscorr::shared_context(), in.data()) == GC_OK, "unregister: %s", gc_last_error());
         }
+    // register -> unregister -> register -> unregister of ONE array, then a call into it: the second unregister must
+    // find the live registration, the third must fail, and the call must stage its window instead of reading through a stale view
+    {
+        gc_ctx* ctx = gnsscorr::shared_context();
+        const size_t bytes = in.size() * sizeof(in[0]);
+        pool[0].set_input_output_vectors(&outs[0], in.data());
+        for (int round = 0; round < 2; round++)
+            {
+                EXPECT(gc_ctx_register_host_buffer(ctx, in.data(), bytes) == GC_OK, "re-register %d: %s", round, gc_last_error());
+                EXPECT(call(0), "call on the registered buffer");
+                EXPECT(gc_ctx_unregister_host_buffer(ctx, in.data()) == GC_OK, "unregister %d: %s", round, gc_last_error());
+            }
+        EXPECT(gc_ctx_unregister_host_buffer(ctx, in.data()) != GC_OK, "a third unregister must report that nothing is registered");
+        outs[0] = outs[1] = outs[2] = std::complex<float>(0.f, 0.f);
+        EXPECT(call(0), "call after the buffer was unregistered");
+        std::complex<double> want[3];
+        want_at(0, shifts[0].data(), want);
+        for (int k = 0; k < 3; k++)
+            EXPECT(std::abs(std::complex<double>(outs[k]) - want[k]) <= 2e-4 * (std::abs(want[k]) + 50.0), "after unregister, tap %d: (%g,%g) vs (%g,%g)", k, outs[k].real(),
+                outs[k].imag(), want[k].real(), want[k].imag());
+    }
 }
 
 int main(int argc, char** argv)

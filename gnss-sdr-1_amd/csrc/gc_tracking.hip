@@ -6,6 +6,7 @@
 //                        and, with complex chips, of Cpu_Multicorrelator
 //                        (src/algorithms/tracking/libs/cpu_multicorrelator.h:46-64)
 #include "gc_internal.h"
+#include "gc_l1_batcher.h"
 #include "gc_stream.h"
 #include "trk_kernels.h"
 #include <algorithm>
@@ -566,172 +567,10 @@ static void correlator_release(gc_correlator* c)
 }
 
 // -----------------------------------------------------------------------------
-// Level-1 epoch batcher (SURVEY.md section 7 "Latency vs batching", section 8b "one instance per channel thread").
-//
-// The reference runs one Cpu_Multicorrelator_Real_Codes per channel on that channel's scheduler thread and every thread
-// calls Carrier_wipeoff_multicorrelator_resampler once per code period (dll_pll_veml_tracking.cc:886-911,
-// gnss_flowgraph.cc:496-499).  Here those synchronous calls meet in a per-context queue: a caller that finds a free lane
-// becomes the leader of everything queued at that moment with the same kernel shape (taps, mode, sample format, slices),
-// builds ONE launch for the batch (one TrkChan + gc_epoch_params per request, results scattered to each caller's corr_out)
-// and wakes the others; requests that arrive while a batch is on the GPU form the next one, so the batch size follows the
-// load by itself (group commit: no timer, a lone caller is served at once).  Two lanes (own HIP stream and staging each)
-// keep a batch in preparation while another executes.  Callers that hand in the SAME input pointer (channels reading one
-// GNU Radio buffer position) share one DMA of the window into HBM instead of one PCIe read each.
+// Level-1 epoch batcher: queue / lanes / waiters / window sharing / host-buffer registry live in gc_l1_batcher.h (header-only,
+// no HIP types, exercised on the CPU under ThreadSanitizer by tests/l1_batcher_selftest.cpp); this is its HIP backend: a lane
+// is a HIP stream with page-locked, device-mapped descriptor / result arrays, a launch is ONE trk_launch over the batch.
 // -----------------------------------------------------------------------------
-// What a calling thread sleeps on.  Its own mutex, so that waking a batch's callers does not queue them up on the batcher's
-// mutex; held through shared_ptr by the request and by whoever is about to signal it (the signal is sent after the batcher's
-// mutex is released, when the request may already be gone).
-struct L1Waiter
-{
-    std::mutex m;
-    std::condition_variable cv;
-    bool signaled = false;
-    void wait()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [this] { return signaled; });
-        signaled = false;
-    }
-    void signal()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            signaled = true;
-        }
-        cv.notify_one();
-    }
-};
-
-struct L1Request
-{
-    TrkChan chan;
-    gc_epoch_params params;
-    int n_corr = 0, mode = 0, fmt = 0, n_slices = 1, lds_floats = 0;
-    const char* host_sig = nullptr;    // caller's sig_in
-    size_t sig_bytes = 0;
-    // where the window is read from: (a) a registered host region (region >= 0: no staging copy, device view reg_dev); (b) this
-    // request's page-locked copy (self_copied: made by the calling thread before it queued, in parallel with the others);
-    // (c) deferred: the request overlapped an earlier queued one when it arrived and copied nothing -- the leader of its batch
-    // stages the UNION of overlapping windows once (channels read neighbouring positions of one stream buffer)
-    int region = -1;
-    const char* reg_dev = nullptr;
-    const void* own_dev = nullptr;   // device view of this request's page-locked buffer
-    bool self_copied = false;
-    bool copy_done = false;          // queued and ready to be taken
-    void* out_host = nullptr;
-    size_t out_bytes = 0;
-    gc_status status = GC_OK;
-    char err[200] = "";
-    bool taken = false;
-    std::atomic<bool> done{false};     // set last by the batch's leader; the owner returns on it without taking any lock
-    std::shared_ptr<L1Waiter> waiter;  // the owner thread's
-};
-
-struct L1Lane
-{
-    hipStream_t stream = nullptr;
-    TrkChan* h_chans = nullptr;          // pinned, mapped
-    gc_epoch_params* h_params = nullptr;
-    float2* h_out = nullptr;
-    TrkChan* dv_chans = nullptr;
-    gc_epoch_params* dv_params = nullptr;
-    float2* dv_out = nullptr;
-    float2* d_partial = nullptr;
-    char* d_span = nullptr;              // windows shared by several requests of a batch, copied once
-    size_t span_cap = 0;
-    char* h_span = nullptr;              // page-locked, mapped: where the leader stages unions of overlapping unregistered windows
-    const char* dv_span = nullptr;       // its device view
-    size_t hspan_cap = 0;
-    bool busy = false;
-};
-
-struct L1Region
-{
-    const char* host = nullptr;
-    size_t bytes = 0;
-    const char* dev = nullptr;
-};
-
-struct gc_l1_batcher
-{
-    static constexpr int MAXB = 256, LANES = 2, MAX_SLICES = 64;
-    int device = 0;
-    std::mutex m;
-    std::deque<L1Request*> queue;
-    L1Lane lanes[LANES];
-    std::vector<L1Region> regions;   // gc_ctx_register_host_buffer
-    bool ok = false;
-    int min_second_lane = 16;  // $GNSSCORR_L1_SECOND_LANE: ready calls needed to start a batch while another one is running
-    // statistics (gc_correlator_batch_stats)
-    unsigned long long n_batches = 0, n_requests = 0, n_shared = 0;
-    int max_batch = 0;
-    // $GNSSCORR_L1_TRACE=1: where a batch's time goes (microseconds, summed), printed by gc_correlator_batch_stats
-    double t_prep = 0, t_launch = 0, t_sync = 0, t_scatter = 0, t_queue = 0;
-};
-static double l1_now_us()
-{
-    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-static void l1_batcher_free(void* p)
-{
-    gc_l1_batcher* b = static_cast<gc_l1_batcher*>(p);
-    for (auto& l : b->lanes)
-        {
-            if (l.stream)
-                {
-                    (void)hipStreamSynchronize(l.stream);
-                    (void)hipStreamDestroy(l.stream);
-                }
-            if (l.h_chans) (void)hipHostFree(l.h_chans);
-            if (l.h_params) (void)hipHostFree(l.h_params);
-            if (l.h_out) (void)hipHostFree(l.h_out);
-            (void)hipFree(l.d_partial);
-            (void)hipFree(l.d_span);
-            if (l.h_span) (void)hipHostFree(l.h_span);
-        }
-    for (auto& r : b->regions) (void)hipHostUnregister(const_cast<char*>(r.host));
-    delete b;
-}
-
-static bool l1_span_reserve(L1Lane& lane, size_t need);
-static bool l1_hspan_reserve(L1Lane& lane, size_t need);
-
-// the context's batcher (created by the first caller; NULL if its buffers cannot be set up: callers then use the direct path)
-static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
-{
-    if (void* p = ctx->l1_batcher.load(std::memory_order_acquire)) return static_cast<gc_l1_batcher*>(p)->ok ? static_cast<gc_l1_batcher*>(p) : nullptr;
-    std::lock_guard<std::mutex> lk(ctx->mtx);
-    if (void* p = ctx->l1_batcher.load(std::memory_order_acquire)) return static_cast<gc_l1_batcher*>(p)->ok ? static_cast<gc_l1_batcher*>(p) : nullptr;
-    gc_l1_batcher* b = new gc_l1_batcher();
-    b->device = ctx->device;
-    if (const char* e = std::getenv("GNSSCORR_L1_SECOND_LANE")) b->min_second_lane = std::max(1, std::atoi(e));
-    bool ok = true;
-    for (auto& l : b->lanes)
-        {
-            void* dv = nullptr;
-            ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
-            ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_chans), sizeof(TrkChan) * gc_l1_batcher::MAXB, hipHostMallocMapped) == hipSuccess;
-            ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_params), sizeof(gc_epoch_params) * gc_l1_batcher::MAXB, hipHostMallocMapped) == hipSuccess;
-            ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_out), sizeof(float2) * GC_MAX_TAPS * gc_l1_batcher::MAXB, hipHostMallocMapped) == hipSuccess;
-            ok = ok && hipHostGetDevicePointer(&dv, l.h_chans, 0) == hipSuccess;
-            l.dv_chans = static_cast<TrkChan*>(dv);
-            ok = ok && hipHostGetDevicePointer(&dv, l.h_params, 0) == hipSuccess;
-            l.dv_params = static_cast<gc_epoch_params*>(dv);
-            ok = ok && hipHostGetDevicePointer(&dv, l.h_out, 0) == hipSuccess;
-            l.dv_out = static_cast<float2*>(dv);
-            ok = ok && hipMalloc(&l.d_partial, sizeof(float2) * GC_MAX_TAPS * gc_l1_batcher::MAX_SLICES * gc_l1_batcher::MAXB) == hipSuccess;
-            // the span buffers of a typical batch up front (page-locking megabytes takes milliseconds: not inside a call)
-            if (ok) (void)l1_span_reserve(l, (size_t)8 << 20);
-            if (ok) (void)l1_hspan_reserve(l, (size_t)8 << 20);
-        }
-    if (!ok) (void)hipGetLastError();
-    b->ok = ok;
-    ctx->l1_batcher_free = &l1_batcher_free;
-    ctx->l1_batcher.store(b, std::memory_order_release);
-    return ok ? b : nullptr;
-}
-
 // host (mapped / registered) -> HBM copy of a shared window on the lane's stream: a kernel launch costs the calling thread
 // less than a hipMemcpyAsync, and the tracking kernel behind it needs no other ordering
 __global__ void l1_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int tail_bytes)
@@ -740,355 +579,161 @@ __global__ void l1_copy_kernel(const uint4* __restrict__ src, uint4* __restrict_
     if (blockIdx.x == 0 && (int)threadIdx.x < tail_bytes)  // never reads past the end of the caller's memory
         reinterpret_cast<char*>(dst + n16)[threadIdx.x] = reinterpret_cast<const char*>(src + n16)[threadIdx.x];
 }
-// src_dev_view and dst are 16-byte aligned
-static hipError_t l1_copy(hipStream_t st, const void* src_dev_view, void* dst, size_t bytes)
-{
-    const size_t n16 = bytes / 16;
-    const unsigned blocks = (unsigned)std::min<size_t>(256, (n16 + 255) / 256);
-    hipLaunchKernelGGL(l1_copy_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, static_cast<const uint4*>(src_dev_view), static_cast<uint4*>(dst), n16,
-        (int)(bytes - n16 * 16));
-    return hipGetLastError();
-}
 
-// grows the lane's shared-window buffer (the lane is idle: nothing reads the old one)
-static bool l1_span_reserve(L1Lane& lane, size_t need)
+struct L1HipBackend
 {
-    if (need <= lane.span_cap) return true;
-    (void)hipFree(lane.d_span);
-    lane.d_span = nullptr;
-    lane.span_cap = 0;
-    need = (need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
-    if (hipMalloc(&lane.d_span, need) != hipSuccess)
-        {
-            (void)hipGetLastError();
-            return false;
-        }
-    lane.span_cap = need;
-    return true;
-}
-
-static bool l1_hspan_reserve(L1Lane& lane, size_t need)
-{
-    if (need <= lane.hspan_cap) return true;
-    if (lane.h_span) (void)hipHostFree(lane.h_span);
-    lane.h_span = nullptr;
-    lane.hspan_cap = 0;
-    need = (need + ((size_t)4 << 20)) & ~(((size_t)1 << 20) - 1);  // page-locking is slow: grow in large steps
-    void* dv = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&lane.h_span), need, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dv, lane.h_span, 0) != hipSuccess)
-        {
-            (void)hipGetLastError();
-            if (lane.h_span) (void)hipHostFree(lane.h_span);
-            lane.h_span = nullptr;
-            return false;
-        }
-    lane.dv_span = static_cast<const char*>(dv);
-    lane.hspan_cap = need;
-    return true;
-}
-
-// runs one batch on `lane` (no lock held); fills status / err of every request
-static void l1_run_batch(gc_l1_batcher* b, L1Lane& lane, std::vector<L1Request*>& batch, const std::vector<L1Region>& regions, int* n_shared_out)
-{
-    gc_device_guard g(b->device);
-    const double ta = l1_now_us();
-    const int B = (int)batch.size();
-    const L1Request& k = *batch[0];
-    int lds_floats = 0;
-    for (L1Request* r : batch) lds_floats = std::max(lds_floats, r->lds_floats);
-    hipError_t e = hipSuccess;
-    int n_shared = 0;
-    size_t span_off = 0;
-    // room for every shared window of this batch, reserved before any pointer into the buffers is handed out
-    bool can_share = false, can_stage = false;
+    typedef TrkChan Chan;
+    typedef gc_epoch_params Params;
+    static constexpr int MAX_SLICES = 64;
+    struct Lane
     {
-        size_t need = 0, need_host = 0;
-        for (L1Request* r : batch)
-            if (r->sig_bytes > 0)
-                {
-                    need += r->sig_bytes + 512;
-                    if (r->region < 0) need_host += r->sig_bytes + 512;
-                }
-        can_share = l1_span_reserve(lane, need);
-        can_stage = need_host == 0 || l1_hspan_reserve(lane, need_host);
+        hipStream_t stream = nullptr;
+        TrkChan* h_chans = nullptr;  // pinned, mapped
+        gc_epoch_params* h_params = nullptr;
+        char* h_out = nullptr;
+        TrkChan* dv_chans = nullptr;
+        gc_epoch_params* dv_params = nullptr;
+        float2* dv_out = nullptr;
+        float2* d_partial = nullptr;
+        char* d_span = nullptr;  // windows shared by several requests of a batch, copied once
+        size_t span_cap = 0;
+        char* h_span = nullptr;         // page-locked, mapped: where the leader stages unions of overlapping unregistered windows
+        const char* dv_span = nullptr;  // its device view
+        size_t hspan_cap = 0;
+    };
+    int device = 0;
+    struct Guard
+    {
+        gc_device_guard g;
+        explicit Guard(L1HipBackend& b) : g(b.device) {}
+    };
+    bool lane_init(Lane& l, int maxb, int max_out_bytes)
+    {
+        void* dv = nullptr;
+        bool ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_chans), sizeof(TrkChan) * maxb, hipHostMallocMapped) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_params), sizeof(gc_epoch_params) * maxb, hipHostMallocMapped) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void**>(&l.h_out), (size_t)max_out_bytes * maxb, hipHostMallocMapped) == hipSuccess;
+        ok = ok && hipHostGetDevicePointer(&dv, l.h_chans, 0) == hipSuccess;
+        l.dv_chans = static_cast<TrkChan*>(dv);
+        ok = ok && hipHostGetDevicePointer(&dv, l.h_params, 0) == hipSuccess;
+        l.dv_params = static_cast<gc_epoch_params*>(dv);
+        ok = ok && hipHostGetDevicePointer(&dv, l.h_out, 0) == hipSuccess;
+        l.dv_out = static_cast<float2*>(dv);
+        ok = ok && hipMalloc(&l.d_partial, sizeof(float2) * GC_MAX_TAPS * MAX_SLICES * maxb) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
     }
-    // (1) windows inside a registered host region: the callers' windows of one region overlap when the channels read
-    // neighbouring positions of one stream buffer.  When the union of the windows is clearly smaller than their sum, the union
-    // crosses PCIe ONCE (one DMA straight from the caller's page-locked memory into HBM) and every request reads its piece of
-    // it; otherwise each request reads its window from the registered memory in place.
-    for (size_t ri = 0; ri < regions.size() && e == hipSuccess && can_share; ri++)
-        {
-            const char* lo = nullptr;
-            const char* hi = nullptr;
-            size_t sum = 0;
-            int members = 0;
-            for (L1Request* r : batch)
-                if (r->region == (int)ri && r->sig_bytes > 0)
-                    {
-                        lo = (!lo || r->host_sig < lo) ? r->host_sig : lo;
-                        hi = (!hi || r->host_sig + r->sig_bytes > hi) ? r->host_sig + r->sig_bytes : hi;
-                        sum += r->sig_bytes;
-                        members++;
-                    }
-            if (members < 2) continue;
-            // the copy starts on a 16-byte boundary of the caller's memory, so every window keeps its alignment
-            const char* lo_al = lo - ((uintptr_t)lo & 15);
-            if (lo_al < regions[ri].host) continue;  // an unaligned region start: read in place
-            const size_t uni = (size_t)(hi - lo_al);
-            const size_t off = (span_off + 255) & ~(size_t)255;
-            if (uni * 3 > sum * 2 || off + uni > lane.span_cap) continue;  // nothing to gain: read in place
-            e = l1_copy(lane.stream, regions[ri].dev + (lo_al - regions[ri].host), lane.d_span + off, uni);
-            for (L1Request* r : batch)
-                if (r->region == (int)ri && r->sig_bytes > 0)
-                    {
-                        r->chan.iq = lane.d_span + off + (r->host_sig - lo_al);
-                        n_shared++;
-                    }
-            span_off = off + uni;
-        }
-    // (2) unregistered input.  A window staged by its own calling thread is read in place from that thread's page-locked buffer.
-    // Windows that overlap (identical pointers; channels at neighbouring read positions of one GNU Radio buffer) form a
-    // cluster: the leader copies the cluster's UNION once from the callers' memory -- every byte of it lies inside the window
-    // of some member, and every member is blocked in its synchronous call, so the memory is valid and stable -- into the lane's
-    // page-locked span, one copy kernel moves it into HBM and each member reads its piece there.
-    size_t hoff = 0;
+    void lane_free(Lane& l)
     {
-        std::vector<L1Request*> un;
-        for (L1Request* r : batch)
-            if (r->region < 0 && r->sig_bytes > 0) un.push_back(r);
-        std::sort(un.begin(), un.end(), [](const L1Request* a, const L1Request* c) { return a->host_sig < c->host_sig; });
-        for (size_t i = 0; i < un.size() && e == hipSuccess;)
+        if (l.stream)
             {
-                size_t j = i + 1;
-                const char* lo = un[i]->host_sig;
-                const char* hi = lo + un[i]->sig_bytes;
-                size_t sum = un[i]->sig_bytes;
-                bool any_deferred = !un[i]->self_copied;
-                while (j < un.size() && un[j]->host_sig <= hi)
-                    {
-                        hi = std::max(hi, un[j]->host_sig + un[j]->sig_bytes);
-                        sum += un[j]->sig_bytes;
-                        any_deferred |= !un[j]->self_copied;
-                        j++;
-                    }
-                const size_t uni = (size_t)(hi - lo), lead = (uintptr_t)lo & 15;
-                const bool cluster = (j - i >= 2) && (any_deferred || uni * 3 <= sum * 2);
-                if ((cluster || any_deferred) && !can_stage)
-                    {
-                        e = hipErrorOutOfMemory;
-                        break;
-                    }
-                if (cluster)
-                    {
-                        const size_t off = (hoff + 255) & ~(size_t)255;
-                        std::memcpy(lane.h_span + off + lead, lo, uni);
-                        hoff = off + lead + uni;
-                        const size_t doff = (span_off + 255) & ~(size_t)255;
-                        if (can_share && doff + lead + uni <= lane.span_cap)
-                            {
-                                e = l1_copy(lane.stream, lane.dv_span + off, lane.d_span + doff, lead + uni);
-                                for (size_t t = i; t < j; t++) un[t]->chan.iq = lane.d_span + doff + lead + (un[t]->host_sig - lo);
-                                span_off = doff + lead + uni;
-                            }
-                        else
-                            for (size_t t = i; t < j; t++) un[t]->chan.iq = lane.dv_span + off + lead + (un[t]->host_sig - lo);  // read in place over PCIe
-                        n_shared += (int)(j - i);
-                    }
-                else
-                    for (size_t t = i; t < j; t++)
-                        {
-                            L1Request* r = un[t];
-                            if (r->self_copied)
-                                r->chan.iq = r->own_dev;
-                            else
-                                {
-                                    // deferred, but what it overlapped went into another batch: the leader stages this window
-                                    const size_t off = (hoff + 255) & ~(size_t)255, ld = (uintptr_t)r->host_sig & 15;
-                                    std::memcpy(lane.h_span + off + ld, r->host_sig, r->sig_bytes);
-                                    hoff = off + ld + r->sig_bytes;
-                                    r->chan.iq = lane.dv_span + off + ld;
-                                }
-                        }
-                i = j;
+                (void)hipStreamSynchronize(l.stream);
+                (void)hipStreamDestroy(l.stream);
             }
+        if (l.h_chans) (void)hipHostFree(l.h_chans);
+        if (l.h_params) (void)hipHostFree(l.h_params);
+        if (l.h_out) (void)hipHostFree(l.h_out);
+        (void)hipFree(l.d_partial);
+        (void)hipFree(l.d_span);
+        if (l.h_span) (void)hipHostFree(l.h_span);
+        l = Lane();
     }
-    for (int i = 0; i < B; i++)
-        {
-            lane.h_chans[i] = batch[i]->chan;
-            lane.h_params[i] = batch[i]->params;
-        }
-    const double tb = l1_now_us();
-    if (e == hipSuccess)
-        e = trk_launch(k.n_corr, k.mode, k.fmt, lane.stream, lane.dv_chans, lane.dv_params, lane.dv_out, lane.d_partial, B, 1, k.n_slices, lds_floats, false);
-    const double tc = l1_now_us();
-    if (e == hipSuccess) e = hipStreamSynchronize(lane.stream);
-    const double td = l1_now_us();
-    for (int i = 0; i < B; i++)
-        {
-            L1Request* r = batch[i];
-            if (e != hipSuccess)
-                {
-                    r->status = GC_ERR_HIP;
-                    std::snprintf(r->err, sizeof r->err, "tracking kernel (batch of %d) failed: %s", B, hipGetErrorString(e));
-                }
-            else
-                std::memcpy(r->out_host, reinterpret_cast<const char*>(lane.h_out) + (size_t)i * r->out_bytes, r->out_bytes);
-        }
-    *n_shared_out = n_shared;
-    const double te = l1_now_us();
-    std::lock_guard<std::mutex> lk(b->m);
-    b->t_prep += tb - ta;
-    b->t_launch += tc - tb;
-    b->t_sync += td - tc;
-    b->t_scatter += te - td;
-}
+    // grows the lane's shared-window buffer (the lane is idle: nothing reads the old one)
+    bool span_reserve(Lane& lane, size_t need)
+    {
+        if (need <= lane.span_cap) return true;
+        (void)hipFree(lane.d_span);
+        lane.d_span = nullptr;
+        lane.span_cap = 0;
+        need = (need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+        if (hipMalloc(&lane.d_span, need) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return false;
+            }
+        lane.span_cap = need;
+        return true;
+    }
+    bool hspan_reserve(Lane& lane, size_t need)
+    {
+        if (need <= lane.hspan_cap) return true;
+        if (lane.h_span) (void)hipHostFree(lane.h_span);
+        lane.h_span = nullptr;
+        lane.hspan_cap = 0;
+        need = (need + ((size_t)4 << 20)) & ~(((size_t)1 << 20) - 1);  // page-locking is slow: grow in large steps
+        void* dv = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&lane.h_span), need, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dv, lane.h_span, 0) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                if (lane.h_span) (void)hipHostFree(lane.h_span);
+                lane.h_span = nullptr;
+                return false;
+            }
+        lane.dv_span = static_cast<const char*>(dv);
+        lane.hspan_cap = need;
+        return true;
+    }
+    // src_dev_view and dst are 16-byte aligned
+    int copy(Lane& lane, const void* src_dev_view, void* dst, size_t bytes)
+    {
+        const size_t n16 = bytes / 16;
+        const unsigned blocks = (unsigned)std::min<size_t>(256, (n16 + 255) / 256);
+        hipLaunchKernelGGL(l1_copy_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, lane.stream, static_cast<const uint4*>(src_dev_view), static_cast<uint4*>(dst), n16,
+            (int)(bytes - n16 * 16));
+        return (int)hipGetLastError();
+    }
+    template <class Rq>
+    int launch(Lane& lane, const Rq& k, int B, int lds_floats)
+    {
+        return (int)trk_launch(k.n_corr, k.mode, k.fmt, lane.stream, lane.dv_chans, lane.dv_params, lane.dv_out, lane.d_partial, B, 1, k.n_slices, lds_floats, false);
+    }
+    int wait(Lane& lane) { return (int)hipStreamSynchronize(lane.stream); }
+    int oom_error() const { return (int)hipErrorOutOfMemory; }
+    const char* error_string(int e) const { return hipGetErrorString((hipError_t)e); }
+    void host_unregister(const void* base) { (void)hipHostUnregister(const_cast<void*>(base)); }
+};
 
-static bool l1_same_shape(const L1Request* a, const L1Request* b)
+typedef gc_l1_batcher_t<L1HipBackend> gc_l1_batcher;
+typedef gc_l1_batcher::Request L1Request;
+
+// the backend lives beside the batcher that points at it
+struct L1Holder
 {
-    return a->n_corr == b->n_corr && a->mode == b->mode && a->fmt == b->fmt && a->n_slices == b->n_slices;
+    L1HipBackend be;
+    gc_l1_batcher* bat = nullptr;
+    ~L1Holder() { delete bat; }
+};
+
+static void l1_batcher_free(void* p)
+{
+    L1Holder* h = static_cast<L1Holder*>(p);
+    gc_device_guard g(h->be.device);
+    delete h;
 }
 
-// a request the next leader can take: its window is in place (own copy finished, or a registered region)
-static bool l1_ready(const L1Request* r) { return !r->taken && r->copy_done; }
+// the context's batcher (created by the first caller; NULL if its buffers cannot be set up: callers then use the direct path)
+static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
+{
+    auto usable = [](void* p) -> gc_l1_batcher* {
+        L1Holder* h = static_cast<L1Holder*>(p);
+        return h->bat->ok() ? h->bat : nullptr;
+    };
+    if (void* p = ctx->l1_batcher.load(std::memory_order_acquire)) return usable(p);
+    std::lock_guard<std::mutex> lk(ctx->mtx);
+    if (void* p = ctx->l1_batcher.load(std::memory_order_acquire)) return usable(p);
+    L1Holder* h = new L1Holder();
+    h->be.device = ctx->device;
+    h->bat = new gc_l1_batcher(&h->be, (int)(sizeof(float2) * GC_MAX_TAPS));
+    if (const char* e = std::getenv("GNSSCORR_L1_SECOND_LANE")) h->bat->min_second_lane = std::max(1, std::atoi(e));
+    ctx->l1_batcher_free = &l1_batcher_free;
+    ctx->l1_batcher.store(h, std::memory_order_release);
+    return usable(h);
+}
 
 static gc_status l1_submit(gc_l1_batcher* b, L1Request* rq, void* own_pinned, const void* own_pinned_dev)
 {
-    const double t_in = l1_now_us();
-    struct Acc
-    {
-        gc_l1_batcher* b;
-        double t0;
-        ~Acc() { b->t_queue += l1_now_us() - t0; }  // runs with the lock released: a statistic, not a synchronised counter
-    } acc{b, t_in};
-    static thread_local std::shared_ptr<L1Waiter> my_waiter = std::make_shared<L1Waiter>();
-    rq->waiter = my_waiter;
-    std::unique_lock<std::mutex> lk(b->m);
-    // registered region?
-    for (size_t i = 0; i < b->regions.size(); i++)
-        {
-            const L1Region& g = b->regions[i];
-            if (rq->host_sig >= g.host && rq->host_sig + rq->sig_bytes <= g.host + g.bytes)
-                {
-                    rq->region = (int)i;
-                    rq->reg_dev = g.dev + (rq->host_sig - g.host);
-                    rq->chan.iq = rq->reg_dev;
-                    rq->copy_done = true;
-                    break;
-                }
-        }
-    // the staged copy keeps the 16-byte phase of the caller's pointer, like the shared and the registered paths do: the kernel's
-    // pair alignment, and with it the order of its sums, is then the same however the window reaches the GPU
-    const size_t own_lead = (uintptr_t)rq->host_sig & 15;
-    rq->own_dev = static_cast<const char*>(own_pinned_dev) + own_lead;
-    if (rq->region < 0 && rq->sig_bytes > 0)
-        {
-            // an earlier, still queued call of the same kernel shape whose window overlaps this one: copy nothing, the leader of
-            // the batch stages the union once
-            for (L1Request* r : b->queue)
-                if (!r->taken && r->region < 0 && r->sig_bytes > 0 && l1_same_shape(r, rq) && rq->host_sig < r->host_sig + r->sig_bytes &&
-                    r->host_sig < rq->host_sig + rq->sig_bytes)
-                    {
-                        rq->copy_done = true;
-                        break;
-                    }
-        }
-    else
-        rq->copy_done = true;
-    b->queue.push_back(rq);
-    bool need_copy = !rq->copy_done;
-    for (;;)
-        {
-            if (need_copy)
-                {
-                    lk.unlock();
-                    if (rq->sig_bytes > 0) std::memcpy(static_cast<char*>(own_pinned) + own_lead, rq->host_sig, rq->sig_bytes);
-                    lk.lock();
-                    rq->self_copied = true;
-                    rq->copy_done = true;
-                    need_copy = false;
-                }
-            if (rq->done.load(std::memory_order_acquire)) break;
-            L1Lane* lane = nullptr;
-            if (!rq->taken)
-                for (auto& l : b->lanes)
-                    if (!l.busy)
-                        {
-                            lane = &l;
-                            break;
-                        }
-            const L1Request* key = nullptr;
-            if (lane)
-                {
-                    int n_ready = 0;
-                    bool other_busy = false;
-                    for (auto& l : b->lanes) other_busy |= l.busy;
-                    for (L1Request* r : b->queue)
-                        if (l1_ready(r))
-                            {
-                                if (!key) key = r;
-                                n_ready++;
-                            }
-                    // A batch costs about the same whether it carries one call or fifty (launch + completion latency), so a
-                    // second lane is opened only for a batch worth it; a handful of calls wait for the running batch to finish
-                    // and are joined by everything that arrives meanwhile.
-                    if (other_busy && n_ready < b->min_second_lane) key = nullptr;
-                }
-            if (!lane || !key)
-                {
-                    // sleep on this thread's own waiter: whoever completes the request, frees a lane for it or detaches it
-                    // from its representative signals it
-                    lk.unlock();
-                    rq->waiter->wait();
-                    if (rq->done.load(std::memory_order_acquire)) return rq->status != GC_OK ? gc_fail(rq->status, "%s", rq->err) : GC_OK;
-                    lk.lock();
-                    continue;
-                }
-            // lead: everything queued right now with the shape of the oldest ready request
-            std::vector<L1Request*> batch;
-            for (auto it = b->queue.begin(); it != b->queue.end() && (int)batch.size() < gc_l1_batcher::MAXB;)
-                {
-                    L1Request* r = *it;
-                    if (!r->taken && r->copy_done && l1_same_shape(r, key))
-                        {
-                            r->taken = true;
-                            batch.push_back(r);
-                            it = b->queue.erase(it);
-                        }
-                    else
-                        ++it;
-                }
-            const std::vector<L1Region> regions = b->regions;
-            lane->busy = true;
-            lk.unlock();
-            int n_shared = 0;
-            l1_run_batch(b, *lane, batch, regions, &n_shared);
-            lk.lock();
-            lane->busy = false;
-            b->n_batches++;
-            b->n_requests += batch.size();
-            b->n_shared += (unsigned long long)n_shared;
-            b->max_batch = std::max(b->max_batch, (int)batch.size());
-            // who to wake, collected under the lock and signalled after it is released: the batch's callers, the owner of the
-            // oldest ready request (it leads next), and followers whose representative left without them
-            std::vector<std::shared_ptr<L1Waiter>> wake;
-            bool handed = false;
-            for (L1Request* r : b->queue)
-                if (r != rq && !handed && l1_ready(r))
-                    {
-                        wake.push_back(r->waiter);
-                        handed = true;
-                    }
-            for (L1Request* r : batch)
-                {
-                    if (r != rq) wake.push_back(r->waiter);
-                    r->done.store(true, std::memory_order_release);  // r may be gone from here on (its owner returns on the flag)
-                }
-            lk.unlock();
-            for (auto& w : wake) w->signal();
-            lk.lock();
-        }
-    lk.unlock();
-    if (rq->status != GC_OK) return gc_fail(rq->status, "%s", rq->err);
+    if (b->submit(rq, own_pinned, own_pinned_dev) != gc_l1_batcher::ST_OK) return gc_fail(GC_ERR_HIP, "%s", rq->err);
     return GC_OK;
 }
 
@@ -1370,14 +1015,17 @@ gc_status gc_ctx_register_host_buffer(gc_ctx* ctx, const void* base, size_t byte
     if (!b) return gc_fail(GC_ERR_HIP, "gc_ctx_register_host_buffer: the batcher's buffers could not be set up");
     void* dv = nullptr;
     hipError_t e = hipHostRegister(const_cast<void*>(base), bytes, hipHostRegisterMapped);
-    if (e == hipSuccess) e = hipHostGetDevicePointer(&dv, const_cast<void*>(base), 0);
+    if (e == hipSuccess)
+        {
+            e = hipHostGetDevicePointer(&dv, const_cast<void*>(base), 0);
+            if (e != hipSuccess) (void)hipHostUnregister(const_cast<void*>(base));
+        }
     if (e != hipSuccess)
         {
             (void)hipGetLastError();
             return gc_fail(GC_ERR_HIP, "gc_ctx_register_host_buffer: %s (the correlators keep staging their windows)", hipGetErrorString(e));
         }
-    std::lock_guard<std::mutex> lk(b->m);
-    b->regions.push_back(L1Region{static_cast<const char*>(base), bytes, static_cast<const char*>(dv)});
+    b->add_region(base, bytes, dv);
     return GC_OK;
 }
 
@@ -1387,43 +1035,28 @@ gc_status gc_ctx_unregister_host_buffer(gc_ctx* ctx, const void* base)
     gc_device_guard g(ctx->device);
     void* p = ctx->l1_batcher.load(std::memory_order_acquire);
     if (!p) return gc_fail(GC_ERR_STATE, "gc_ctx_unregister_host_buffer: nothing is registered");
-    gc_l1_batcher* b = static_cast<gc_l1_batcher*>(p);
-    std::unique_lock<std::mutex> lk(b->m);
-    for (size_t i = 0; i < b->regions.size(); i++)
-        if (b->regions[i].host == base)
-            {
-                // calls in flight hold indices into the list: the slot stays, emptied
-                b->regions[i].bytes = 0;
-                lk.unlock();
-                for (auto& l : b->lanes) (void)hipStreamSynchronize(l.stream);
-                (void)hipHostUnregister(const_cast<void*>(base));
-                return GC_OK;
-            }
-    return gc_fail(GC_ERR_STATE, "gc_ctx_unregister_host_buffer: %p is not registered", base);
+    // live registrations only; returns once no queued or running call reads through the buffer's device view and it is unpinned
+    if (!static_cast<L1Holder*>(p)->bat->remove_region(base)) return gc_fail(GC_ERR_STATE, "gc_ctx_unregister_host_buffer: %p is not registered", base);
+    return GC_OK;
 }
 
 gc_status gc_correlator_batch_stats(gc_ctx* ctx, uint64_t* n_batches, uint64_t* n_requests, uint64_t* n_shared_windows, int* max_batch)
 {
     GC_REQUIRE(ctx, "gc_correlator_batch_stats: NULL context");
-    unsigned long long nb = 0, nr = 0, ns = 0;
-    int mb = 0;
+    gc_l1_batcher::Stats st;
     if (void* p = ctx->l1_batcher.load(std::memory_order_acquire))
         {
-            gc_l1_batcher* b = static_cast<gc_l1_batcher*>(p);
-            std::lock_guard<std::mutex> lk(b->m);
-            nb = b->n_batches;
-            nr = b->n_requests;
-            ns = b->n_shared;
-            mb = b->max_batch;
+            st = static_cast<L1Holder*>(p)->bat->stats();
             if (const char* e = std::getenv("GNSSCORR_L1_TRACE"))
-                if (e[0] == '1' && nb)
+                if (e[0] == '1' && st.n_batches)
                     std::fprintf(stderr, "gnsscorr level-1 batcher: %llu batches, %llu calls; per batch: prepare %.1f us, launch %.1f us, wait %.1f us, scatter %.1f us; per call in the batcher %.1f us\n",
-                        nb, nr, b->t_prep / nb, b->t_launch / nb, b->t_sync / nb, b->t_scatter / nb, b->t_queue / (nr ? nr : 1));
+                        st.n_batches, st.n_requests, st.t_prep / st.n_batches, st.t_launch / st.n_batches, st.t_sync / st.n_batches, st.t_scatter / st.n_batches,
+                        st.t_queue / (st.n_requests ? st.n_requests : 1));
         }
-    if (n_batches) *n_batches = nb;
-    if (n_requests) *n_requests = nr;
-    if (n_shared_windows) *n_shared_windows = ns;
-    if (max_batch) *max_batch = mb;
+    if (n_batches) *n_batches = st.n_batches;
+    if (n_requests) *n_requests = st.n_requests;
+    if (n_shared_windows) *n_shared_windows = st.n_shared;
+    if (max_batch) *max_batch = st.max_batch;
     return GC_OK;
 }
 

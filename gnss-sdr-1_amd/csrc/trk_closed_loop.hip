@@ -1136,6 +1136,19 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
     auto cancel_all = [&]() {
         for (size_t k = 0; k < tickets.size(); k++) gc_stream_cancel_read(rings[k], tickets[k]);
     };
+    // Between the reservations below and their commit behind the launch NOTHING may return without releasing the reader slots: a slot
+    // left `pending` blocks every later push that would evict below its floor, and gc_stream_drop's drain, for ever.
+#define LOOP_HIP_OR_CANCEL(call)                                                                                              \
+    do                                                                                                                        \
+        {                                                                                                                     \
+            hipError_t e_ = (call);                                                                                           \
+            if (e_ != hipSuccess)                                                                                             \
+                {                                                                                                             \
+                    cancel_all();                                                                                             \
+                    return gc_fail(GC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+                }                                                                                                             \
+        }                                                                                                                     \
+    while (0)
     tickets.resize(rings.size());
     for (size_t k = 0; k < rings.size(); k++)
         {
@@ -1182,7 +1195,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
     do                                                                                                                                        \
         {                                                                                                                                     \
             if (lds_bytes > 48 * 1024)                                                                                                        \
-                GC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, TH, FM, DA>),                            \
+                LOOP_HIP_OR_CANCEL(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, TH, FM, DA>),                            \
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                                                             \
             hipLaunchKernelGGL((trk_closed_loop_kernel<NT, TH, FM, DA>), dim3(l->n_channels), dim3(TH), lds_bytes, st, l->d_chans, dev_records, \
                 n_epochs, lds_table_floats, limits);                                                                                          \
@@ -1210,7 +1223,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
     do                                                                                                                                        \
         {                                                                                                                                     \
             if (lds_bytes_hd > 48 * 1024)                                                                                                     \
-                GC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, 256, FM, DA, true>),                     \
+                LOOP_HIP_OR_CANCEL(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, 256, FM, DA, true>),                     \
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_hd));                                                          \
             hipLaunchKernelGGL((trk_closed_loop_kernel<NT, 256, FM, DA, true>), dim3(l->n_channels), dim3(256), lds_bytes_hd, st, l->d_chans,  \
                 dev_records, n_epochs, lds_table_floats, limits);                                                                             \
@@ -1262,19 +1275,30 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
                 return gc_fail(GC_ERR_HIP, "gc_trk_loop_run: kernel launch failed: %s", hipGetErrorString(le));
             }
     }
-    GC_HIP(hipEventRecord(l->last_launch, st));
-    l->launched = true;
-    if (any_ring)
-        {
-            GC_HIP(hipEventRecord(l->limit_done[slot], st));
-            l->limit_used[slot] = true;
-            l->limit_next = (slot + 1) % gc_trk_loop::LIMIT_SLOTS;
-        }
+#undef LOOP_HIP_OR_CANCEL
+    // the kernel is enqueued: the tickets are committed whatever the event records below return (the error is reported afterwards)
     gc_status out = GC_OK;
+    hipError_t ee = hipEventRecord(l->last_launch, st);
+    l->launched = true;
+    if (ee == hipSuccess && any_ring)
+        {
+            ee = hipEventRecord(l->limit_done[slot], st);
+            if (ee == hipSuccess)
+                {
+                    l->limit_used[slot] = true;
+                    l->limit_next = (slot + 1) % gc_trk_loop::LIMIT_SLOTS;
+                }
+        }
+    if (ee != hipSuccess)
+        {
+            // without its completion event the launch cannot be tracked: wait for it here, then commit
+            (void)hipStreamSynchronize(st);
+            out = gc_fail(GC_ERR_HIP, "gc_trk_loop_run: hipEventRecord failed: %s", hipGetErrorString(ee));
+        }
     for (size_t k = 0; k < rings.size(); k++)
         {
             gc_status rs = gc_stream_end_read(rings[k], st, tickets[k]);
-            if (rs != GC_OK) out = rs;
+            if (rs != GC_OK && out == GC_OK) out = rs;
         }
     return out;
 }

@@ -44,8 +44,14 @@ struct HostPolicy
     {
         while (!query(e)) std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
+    static std::atomic<int>& fail_records() { static std::atomic<int> n{0}; return n; }  // > 0: the next records fail (error path)
     static bool record(HostEvent* e, HostStream* st)
     {
+        if (fail_records().load() > 0)
+            {
+                fail_records().fetch_sub(1);
+                return false;
+            }
         std::lock_guard<std::mutex> lk(gm());
         for (auto& p : recs())
             if (p.first == e)
@@ -74,6 +80,28 @@ int main()
         }
     table.init(ev_ptrs);
     uint64_t head = 0, evicting_below = 0;
+    // ---- error paths of a launch: "reserve, then fail before the enqueue" must cancel, "enqueue, then the event
+    // record fails" must commit -- either way the slot is released, so a push that evicts below its floor does not block and the
+    // teardown drain returns.  A slot left pending would hang here (the test's timeout is the assertion).
+    {
+        std::unique_lock<std::mutex> lk(mtx);
+        auto zero = []() { return (uint64_t)0; };
+        HostStream st;
+        int s0 = table.reserve(lk, 10, zero);
+        table.cancel(s0);                    // the launch was never enqueued
+        int s1 = table.reserve(lk, 20, zero);
+        HostPolicy::fail_records().store(1);
+        const bool ok = table.commit(s1, &st);  // enqueued, but its completion cannot be recorded: reported, slot released
+        table.wait_evictable(lk, 1000);
+        table.drain(lk);
+        int live = 0;
+        for (auto& r : table.readers()) live += r.active;
+        if (ok || live != 0 || s0 < 0 || s1 < 0)
+            {
+                std::printf("reader table: error paths left %d slot(s) reserved (commit returned %d)\n", live, (int)ok);
+                return 1;
+            }
+    }
     std::atomic<bool> stop{false};
     std::atomic<long> bad{0}, reads{0}, behind{0};
 

@@ -134,7 +134,7 @@ def test_cpp_selftests_under_host_asan(prog, tmp_path):
         os.path.join(ad, prog + ".cpp"), "-o", exe, "-L", os.path.join(ROOT, "gnss-sdr-1_amd"), "-lgnsscorr",
         "-Wl,-rpath," + os.path.join(ROOT, "gnss-sdr-1_amd"), "-lpthread"])
     with tempfile.TemporaryDirectory() as d:
-        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", GNSSCORR_SELFTEST_DUMP_DIR=d, GNSSCORR_SELFTEST_NO_TIMING="1")
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", GNSSCORR_SELFTEST_DUMP_DIR=d)
         args = [exe] + ([os.path.join(ROOT, "tests", "golden")] if prog == "adapter_selftest" else [])
         p = subprocess.run(args, capture_output=True, text=True, timeout=900, env=env)
     print(p.stdout[-3000:], p.stderr[-3000:])

@@ -653,6 +653,64 @@ static void test_level1_scales_with_channel_threads()
     }
 }
 
+// Acq_Conf::use_automatic_resampler (pcps_acquisition.cc:756-762): the block searches the decimated stream (resampled_fs) and reports
+// the delay and the sample stamp in samples of the ORIGINAL rate: delay * resampler_ratio - resampler_latency_samples, and
+// rint(samp_count * resampler_ratio).  The same capture through two blocks, with and without the flag.
+static void test_automatic_resampler_rescale(const std::string& dir)
+{
+    auto x = read_iq(dir + "/kat_gps_l1_ca_id1_fs4msps_2ms.dat");
+    Acq_Conf conf;
+    conf.sampled_ms = 1;
+    conf.ms_per_code = 1;
+    conf.samples_per_chip = 4;
+    conf.max_dwells = 1;
+    conf.doppler_max = 5000;
+    conf.fs_in = 4000000;
+    conf.resampled_fs = 4000000;
+    conf.samples_per_ms = 4000.0f;
+    conf.samples_per_code = 4000.0f;
+    conf.use_CFAR_algorithm_flag = true;
+    conf.blocking = true;
+    conf.it_size = sizeof(gr_complex);
+    Acq_Conf rconf = conf;
+    rconf.use_automatic_resampler = true;
+    rconf.fs_in = 10000000;          // the receiver's rate; the block works on the stream decimated to resampled_fs
+    rconf.resampler_ratio = 2.5f;    // fs_in / resampled_fs (gps_l1_ca_pcps_acquisition.cc:75-100)
+    std::vector<gr_complex> code(4008);
+    gc_gps_l1_ca_code_gen_complex_sampled(reinterpret_cast<float*>(code.data()), 1, 4000000, 0, nullptr);
+    Gnss_Synchro syn[2];
+    double delay[2] = {0, 0};
+    uint64_t stamp[2] = {0, 0};
+    for (int k = 0; k < 2; k++)
+        {
+            syn[k].Channel_ID = 0;
+            syn[k].System = 'G';
+            syn[k].Signal[0] = '1';
+            syn[k].Signal[1] = 'C';
+            syn[k].PRN = 1;
+            hip_pcps_acquisition blk(k ? rconf : conf);
+            blk.set_channel(1);
+            blk.set_gnss_synchro(&syn[k]);
+            blk.set_threshold(0.001f);
+            blk.set_doppler_max(5000);
+            blk.set_doppler_step(100);
+            if (k) blk.set_resampler_latency(7);
+            blk.init();
+            blk.set_local_code(code.data());
+            blk.set_state(1);
+            size_t pos = 0;
+            int guard = 0;
+            while (blk.events().empty() && pos < x.size() && guard++ < 100) pos += (size_t)blk.work(x.data() + pos, (int)std::min<size_t>(1024, x.size() - pos));
+            EXPECT(blk.last_status() == GC_OK && blk.events().size() == 1 && blk.events()[0] == 1, "resampler case %d: no positive acquisition (%s)", k, gc_last_error());
+            delay[k] = syn[k].Acq_delay_samples;
+            stamp[k] = syn[k].Acq_samplestamp_samples;
+        }
+    EXPECT(std::abs(delay[1] - (delay[0] * 2.5 - 7.0)) < 1e-9, "Acq_delay_samples %.6f with the resampler, %.6f without: expected %.6f", delay[1], delay[0], delay[0] * 2.5 - 7.0);
+    EXPECT(stamp[1] == (uint64_t)std::llrint((double)stamp[0] * 2.5), "Acq_samplestamp_samples %llu vs rint(%llu * 2.5)", (unsigned long long)stamp[1], (unsigned long long)stamp[0]);
+    EXPECT(syn[1].Acq_doppler_hz == syn[0].Acq_doppler_hz, "Doppler must not be rescaled");
+    std::printf("automatic resampler: delay %.1f -> %.1f samples (x 2.5 - 7), stamp %llu -> %llu\n", delay[0], delay[1], (unsigned long long)stamp[0], (unsigned long long)stamp[1]);
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2)
@@ -671,6 +729,7 @@ int main(int argc, char** argv)
     test_level1_scales_with_channel_threads();
     test_gps_acquisition(argv[1], false);
     test_gps_acquisition(argv[1], true);
+    test_automatic_resampler_rescale(argv[1]);
     test_galileo_acquisition(argv[1]);
     test_glonass_acquisition(argv[1]);
     test_beidou_sizes();

@@ -7,7 +7,8 @@
  * retained, every bool method returns true when the GPU call succeeded (always, in the reference), the constructor leaves the high-dynamics
  * flag set (cpu_multicorrelator_real_codes.cc:49).  The only behavioural addition is
  * last_status(): the reference has no failure path, the GPU has (no device, HIP error);
- * a failed call leaves corr_out untouched, logs to stderr once and is visible there.
+ * a failed call returns false, ZEROES corr_out (the loop then sees no signal rather than the previous epoch's sums), logs to
+ * stderr once and is visible there.
  *
  * In dll_pll_veml_tracking.h the change is one line:
  *     Cpu_Multicorrelator_Real_Codes multicorrelator_cpu;   ->   Hip_Multicorrelator_Real_Codes multicorrelator_cpu;

@@ -75,6 +75,14 @@ bool acq_rows_cols_fusable(const AcqFftPlan& plan);
 hipError_t acq_launch_rows_cols(hipStream_t st, const AcqFftPlan& plan, int n_cells, const float2* A, AcqCellMap mapA, const float2* B,
     AcqCellMap mapB, float2* Q, const float2* wN2, const float2* wN, int epilogue, int n_cells_cols, const float2* Qc, const AcqMagArgs& mag);
 
+// The whole inverse transform of every cell on chip (no inter-pass buffer), for plans acq_inv_fusable() accepts (N = 25 x 1000):
+// grid cell (sat, bin) <- |IFFT(A[bin] * B[sat])|^2 (n_tr = 1), or that of A[bin] and then of A[n_bins + bin] on top (n_tr = 2: a
+// dwell pair); `accumulate`: the grid holds earlier dwells and the first transform adds to them as well.  Same grid, scratch image
+// and block maxima as acq_launch_rows + acq_launch_cols with the MAG / MAG_ACC epilogues.
+bool acq_inv_fusable(const AcqFftPlan& plan);
+hipError_t acq_launch_inv_fused(hipStream_t st, const AcqFftPlan& plan, int n_sats, int n_bins, int n_tr, bool accumulate, const float2* A, const float2* B,
+    const float2* wN2, const float2* wN, const AcqMagArgs& mag, int n_cus);
+
 // phase[bin][n] = float32 running sum of phase_inc[bin] (volk_gnsssdr_s32f_sincos_32fc); out = (cos, sin)
 hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float2* out, int n_bins, int N);
 

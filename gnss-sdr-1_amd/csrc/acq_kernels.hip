@@ -17,6 +17,7 @@
 // element-wise product with conj(FFT(code)) is fused into the row load and
 // |.|^2 + non-coherent accumulation + row maximum into the column epilogue.
 #include "acq_kernels.h"
+#include "gc_internal.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +30,7 @@
                       // schedules worse (0.55 instead of 0.50 ms per search): kept as a knob
 #endif
 typedef float acq_f32x2 __attribute__((ext_vector_type(2)));
+typedef float acq_f32x4 __attribute__((ext_vector_type(4)));
 static __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
 #if ACQ_PK_CMUL
@@ -505,6 +507,7 @@ static __device__ __forceinline__ void rows2_stage(const AcqFftPlan& plan, const
 // vector-memory instructions per thread, most of them 8-byte twiddle loads issued right before their use, and the waves
 // waiting on them: SQ_WAIT_INST_ANY 57 % of the wave cycles at 40 % VALU utilisation).
 // Conditions (checked at compile time): R even, N2 / R even, first stage M even, other stages S even.
+#ifdef GNSSCORR_EXPERIMENTS  // the (re, im)-packed pair kernel: superseded by the planar one below (45.5 vs 43.1 us then), kept for A/B runs
 template <int R, bool INV>
 static __device__ __forceinline__ void tw_powers(float2 w, float2* tw)
 {
@@ -516,7 +519,6 @@ static __device__ __forceinline__ void tw_powers(float2 w, float2* tw)
 template <bool INV>
 static __device__ __forceinline__ float2 tmul(float2 a, float2 w) { return INV ? cmul_conj(a, w) : cmul(a, w); }
 
-typedef float acq_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int R, bool INV, int N2, int S, bool FIRST, bool LAST>
 static __device__ __forceinline__ void rows2p_stage(const AcqFftPlan& plan, const AcqRows2Args& g, float2* lds,
@@ -717,6 +719,8 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS2P_WAVES) void acq_rows2p_kern
 }
 
 // ---- N2 = 1000 = 10 x 10 x 10 on butterfly pairs, PLANAR and packed across the pair ----------------------------------------
+#endif  // GNSSCORR_EXPERIMENTS
+
 // Same decomposition as rows2p_stage (a thread owns butterflies u = 2p, 2p + 1 of a row; 16-byte global accesses; twiddles from
 // seeds), but the registers hold (butterfly 0, butterfly 1) pairs of REAL parts and of IMAGINARY parts: every operation of the
 // radix-10 butterfly is then one packed-FP32 instruction that serves both butterflies with no component shuffles.  The
@@ -1077,7 +1081,7 @@ static bool acq_rows2_config(const AcqFftPlan& plan, int* rpw_out, int* iters)
     if (rpw < 1) rpw = 1;
     if (rpw > 16) rpw = 16;
     static const int rpw_cap = [] {
-        const char* e = std::getenv("GNSSCORR_ACQ_RPW");  // tuning knob: cap on the rows per workgroup
+        const char* e = gc_exp_env("GNSSCORR_ACQ_RPW");  // tuning knob: cap on the rows per workgroup
         return e ? std::atoi(e) : 0;
     }();
     if (rpw_cap > 0 && rpw > rpw_cap) rpw = rpw_cap;
@@ -1340,6 +1344,395 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
     acq_cols_body<N1, INV, EPI>(plan, Q, out, mag, blockIdx.x, gridDim.x, blockIdx.y, p1, sv);
 }
 
+#ifdef GNSSCORR_EXPERIMENTS  // two measured-slower forms of the inverse transform: a cell kept on its CU, and row / column roles in one launch
+// -----------------------------------------------------------------------------------------------------------------------------
+// Whole inverse transform of a cell ON CHIP (N = N1 x 1000, N1 <= 25): * conj(FFT(code)), IFFT, |.|^2 (+=), block maxima
+// (pcps_acquisition.cc:724-739) with NO inter-pass buffer.  The two-pass form moves every cell's N complex values out to the
+// inter-pass buffer and back (16 N bytes per cell: 262 of the 314 MB a batch of 656 cells moves) and its row pass waits on that
+// traffic with four workgroups per CU; here a cell's values never leave the CU: one 512-thread workgroup per CU walks its cells,
+// a thread owns TWO adjacent columns (N1 complex values each: 100 registers at N1 = 25), the 1000-point rows are transformed five
+// at a time (one radix-10 butterfly per thread and stage, three stages through two alternating 40 KB LDS images, like
+// acq_rows3_body with V = float), each finished row is handed to the column owners through the same image, and after the last
+// row the thread transforms its two columns in registers (RegFft) and runs the column pass's epilogue.  HBM sees the grid only;
+// spectra and code spectra (23 MB per search) are re-read from L2 / Infinity Cache.  The next round's 20 inputs per thread are
+// requested one round ahead (40 registers), so with two waves per SIMD the loads are behind ~600 vector instructions.
+// A cell of a dwell PAIR is two transforms by the same workgroup, the first stored (or added to earlier dwells), the second
+// added on top: (grid + first) + second in the order two separate passes add, bit for bit, and each thread re-reads only what it
+// wrote itself.
+// -----------------------------------------------------------------------------------------------------------------------------
+#define ACQ_FUSED_THREADS 512
+#define ACQ_FUSED_RPR 5  // rows per round: 500 of the 512 threads hold one butterfly each
+struct AcqFusedArgs
+{
+    const float2* A;   // spectra [spec][N], row-permuted
+    const float2* B;   // code spectra [sat][N], row-permuted, conjugated
+    const float2* wN2;
+    const float2* wN;
+    AcqMagArgs mag;
+    int n_sats, n_bins;
+    int n_tr;          // transforms per grid cell: 1, or 2 (dwell pair: spectrum `bin`, then spectrum n_bins + `bin`)
+    int accumulate;    // the grid holds earlier dwells: the first transform adds too
+    int n_cells;       // n_sats * n_bins
+};
+typedef VC<float> FC;
+
+template <int N1>
+struct FusedCols
+{
+    float2 a[N1], b[N1];  // columns 2t and 2t + 1, indexed by row k1
+};
+
+// one round: rows k1 = ROUND * 5 + i.  pa / pb: this round's inputs (already in registers); on return they hold the next round's
+// (requested from nxtA / nxtB rows, or untouched when `more` is false)
+template <int N1, int ROUND>
+static __device__ __forceinline__ void acq_fused_round(const AcqFftPlan& plan, const AcqFusedArgs& g, float2* P, float2* Q, float2 (&pa)[10], float2 (&pb)[10],
+    FusedCols<N1>& col, const float2* nxtA, const float2* nxtB, bool more, int t)
+{
+    constexpr int R = 10, N2 = 1000;
+    // The thread's position is laundered through an empty asm once per round: the stage twiddles depend on it alone, and a compiler
+    // that knows it hoists all 36 of them out of the item loop and then spills them (scratch reloads queue behind the input
+    // prefetch in vmcnt order: measured 4x slower than the two-pass form).  Recomputing them costs ~64 instructions per round.
+    asm volatile("" : "+v"(t));
+    const bool act = t < ACQ_FUSED_RPR * 100;
+    const int i = act ? t / 100 : 0, u = t - 100 * i;
+    const int k1 = ROUND * ACQ_FUSED_RPR + i;
+    const bool row_ok = act && k1 < N1;
+    FC a[R], tw[R];
+    // ---- stage 1: butterfly q = u of row i; inputs x[u + 100 j] * code; outputs y[10 u + k] ----
+    if (row_ok)
+        {
+            const float2 sd = g.wN2[plan.tw_off[0] + u];  // w_1000^u
+#pragma unroll
+            for (int j = 0; j < R; j++) a[j] = pk_mul(FC{pa[j].x, pa[j].y}, FC{pb[j].x, pb[j].y});
+            pk_dft10<true>(a);
+            pk_powers10(FC{sd.x, sd.y}, tw);
+            float2* y = P + i * N2 + R * u;
+            y[0] = make_float2(a[0].r, a[0].i);
+#pragma unroll
+            for (int k = 1; k < R; k++)
+                {
+                    const FC o = pk_tmul<true>(a[k], tw[k]);
+                    y[k] = make_float2(o.r, o.i);
+                }
+        }
+    __syncthreads();
+    // the next round's inputs: 20 loads that return while this round's stages 2 and 3 run
+    if (more && act)
+        {
+#pragma unroll
+            for (int j = 0; j < R; j++) pa[j] = nxtA[(size_t)i * N2 + u + 100 * j];
+#pragma unroll
+            for (int j = 0; j < R; j++) pb[j] = nxtB[(size_t)i * N2 + u + 100 * j];
+        }
+    // ---- stage 2: u = 10 q + r; inputs x[u + 100 j]; outputs y[r + 10 k + 100 q] in the other image ----
+    if (row_ok)
+        {
+            const int q = u / 10, r = u - 10 * q;
+            const float2 sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
+            const float2* x = P + i * N2 + u;
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                {
+                    const float2 v = x[100 * j];
+                    a[j] = FC{v.x, v.y};
+                }
+            pk_dft10<true>(a);
+            pk_powers10(FC{sd.x, sd.y}, tw);
+            float2* y = Q + i * N2 + r + 100 * q;
+            y[0] = make_float2(a[0].r, a[0].i);
+#pragma unroll
+            for (int k = 1; k < R; k++)
+                {
+                    const FC o = pk_tmul<true>(a[k], tw[k]);
+                    y[10 * k] = make_float2(o.r, o.i);
+                }
+        }
+    __syncthreads();
+    // ---- stage 3: r = u; inputs x[u + 100 j]; outputs n2 = u + 100 k with the inter-pass twiddle w_N^(k1 n2), back into the first image ----
+    if (row_ok)
+        {
+            const float2 b = g.wN[(size_t)k1 * N2 + u];    // w_N^(k1 u)
+            const float2 d = g.wN[(size_t)k1 * N2 + 100];  // w_N^(100 k1)
+            const float2* x = Q + i * N2 + u;
+#pragma unroll
+            for (int j = 0; j < R; j++)
+                {
+                    const float2 v = x[100 * j];
+                    a[j] = FC{v.x, v.y};
+                }
+            pk_dft10<true>(a);
+            pk_powers10(FC{d.x, d.y}, tw);
+            const FC bb = {b.x, b.y};
+            float2* y = P + i * N2 + u;
+#pragma unroll
+            for (int k = 0; k < R; k++)
+                {
+                    const FC o = pk_tmul<true>(a[k], k == 0 ? bb : pk_mul(bb, tw[k]));
+                    y[100 * k] = make_float2(o.r, o.i);
+                }
+        }
+    __syncthreads();
+    // ---- the finished rows go to their column owners: thread t takes columns 2t, 2t + 1 of the round's rows ----
+    if (act)
+        {
+#pragma unroll
+            for (int ii = 0; ii < ACQ_FUSED_RPR; ii++)
+                if (ROUND * ACQ_FUSED_RPR + ii < N1)
+                    {
+                        const float4 v = *reinterpret_cast<const float4*>(P + ii * N2 + 2 * t);
+                        col.a[ROUND * ACQ_FUSED_RPR + ii] = make_float2(v.x, v.y);
+                        col.b[ROUND * ACQ_FUSED_RPR + ii] = make_float2(v.z, v.w);
+                    }
+        }
+    // no barrier here: the next round's stage 1 writes the OTHER image; its barrier orders these reads before that image is rewritten
+}
+
+// column transform + epilogue of the column pass (acq_cols_body's, two columns per thread); ACC: grid += |.|^2
+template <int N1, bool ACC>
+static __device__ __forceinline__ void acq_fused_epilogue(const AcqFftPlan& plan, const AcqMagArgs& mag, FusedCols<N1>& col, int cell, int t, float* svs,
+    float2 (&nxt_a)[10], float2 (&nxt_b)[10], const float2* nxa, const float2* nxb)
+{
+    constexpr int N2 = 1000;
+    const int N = plan.N;
+    float pa[N1], pb[N1];
+    {
+        float2 y[N1];
+        RegFft<N1, 1, N1, true>::run(col.a, y, plan.w1);
+        const float2* res = RegFft<N1, 1, N1, true>::result_in_first ? col.a : y;
+#pragma unroll
+        for (int k = 0; k < N1; k++) pa[k] = res[k].x * res[k].x + res[k].y * res[k].y;
+        __builtin_amdgcn_sched_barrier(0);
+        RegFft<N1, 1, N1, true>::run(col.b, y, plan.w1);
+        res = RegFft<N1, 1, N1, true>::result_in_first ? col.b : y;
+#pragma unroll
+        for (int k = 0; k < N1; k++) pb[k] = res[k].x * res[k].x + res[k].y * res[k].y;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the columns are dead: the next item's first-round inputs are requested here, behind the grid traffic of this epilogue
+    if (nxa)
+        {
+#pragma unroll
+            for (int j = 0; j < 10; j++) nxt_a[j] = nxa[100 * j];
+#pragma unroll
+            for (int j = 0; j < 10; j++) nxt_b[j] = nxb[100 * j];
+        }
+    float* gr = mag.grid + (size_t)cell * N;
+    const float* gin = gr;  // read before written, by the same thread only
+    const int sat = cell / mag.n_bins, bin = cell - sat * mag.n_bins;
+    float* tmp = (mag.tmp && ACC && bin == mag.tmp_bin) ? mag.tmp + (size_t)sat * N : nullptr;
+    MaxPair best = {-1.0f, 0xffffffffu};
+    // (laundered like the round's: the 50 grid indices and range predicates below depend on the thread's position alone, and hoisted
+    // out of the item loop they occupy ~60 registers for the whole kernel)
+    asm volatile("" : "+v"(t));
+    const bool act = t < 500;
+    const int n2 = 2 * t;
+    typedef float nt_f2 __attribute__((ext_vector_type(2)));
+    // a thread's candidates come in increasing grid index (column 2t, 2t + 1 of row 0, then of row 1, ...), so "the first maximum
+    // wins" (volk_gnsssdr_32f_index_max_32u) is a strict comparison against the best so far
+    if (act && mag.offset == 0 && mag.eff == N)
+        {
+            // the whole row is kept (no bit-transition window): both columns of every row k are an aligned pair inside the grid
+            float2 prev[ACC ? N1 : 1];
+            if (ACC)
+                {
+#pragma unroll
+                    for (int k = 0; k < N1; k++) prev[k] = *reinterpret_cast<const float2*>(gin + n2 + N2 * k);
+                }
+#pragma unroll
+            for (int k = 0; k < N1; k++)
+                {
+                    const int idx = n2 + N2 * k;
+                    const float v0 = ACC ? prev[ACC ? k : 0].x + pa[k] : pa[k];
+                    const float v1 = ACC ? prev[ACC ? k : 0].y + pb[k] : pb[k];
+                    __builtin_nontemporal_store(nt_f2{v0, v1}, reinterpret_cast<nt_f2*>(gr + idx));
+                    if (tmp) *reinterpret_cast<float2*>(tmp + idx) = make_float2(pa[k], pb[k]);
+                    if (v0 > best.v) best = MaxPair{v0, (unsigned)idx};
+                    if (v1 > best.v) best = MaxPair{v1, (unsigned)(idx + 1)};
+                }
+        }
+    else if (act)
+        {
+            // a window [offset, offset + eff) of the row is kept (bit transition): element by element
+#pragma nounroll
+            for (int k = 0; k < N1; k++)
+                {
+                    const int idx = n2 + N2 * k - mag.offset;  // grid column of the first of the two
+                    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < N1; kk++)  // register arrays cannot be indexed by a loop counter: select
+                        if (kk == k)
+                            {
+                                p0 = pa[kk];
+                                p1 = pb[kk];
+                            }
+                    if (idx >= 0 && idx < mag.eff)
+                        {
+                            const float v0 = ACC ? gin[idx] + p0 : p0;
+                            __builtin_nontemporal_store(v0, gr + idx);
+                            if (tmp) tmp[idx] = p0;
+                            if (v0 > best.v) best = MaxPair{v0, (unsigned)idx};
+                        }
+                    if (idx + 1 >= 0 && idx + 1 < mag.eff)
+                        {
+                            const float v1 = ACC ? gin[idx + 1] + p1 : p1;
+                            __builtin_nontemporal_store(v1, gr + idx + 1);
+                            if (tmp) tmp[idx + 1] = p1;
+                            if (v1 > best.v) best = MaxPair{v1, (unsigned)(idx + 1)};
+                        }
+                }
+        }
+    // maxima of the four 256-column blocks the statistics kernel expects (acq_cols_blocks): block = two waves of column owners
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        {
+            MaxPair o;
+            o.v = __shfl_down(best.v, off, 64);
+            o.i = __shfl_down(best.i, off, 64);
+            best = max_pair(best, o);
+        }
+    float* sv = svs;
+    unsigned* si = reinterpret_cast<unsigned*>(svs + ACQ_FUSED_THREADS / 64);
+    const int lane = t & 63, wave = t >> 6;
+    if (lane == 0)
+        {
+            sv[wave] = best.v;
+            si[wave] = best.i;
+        }
+    __syncthreads();
+    if (t < 4)
+        {
+            const MaxPair b = max_pair(MaxPair{sv[2 * t], si[2 * t]}, MaxPair{sv[2 * t + 1], si[2 * t + 1]});
+            mag.blk_max_val[(size_t)cell * 4 + t] = b.v;
+            mag.blk_max_idx[(size_t)cell * 4 + t] = b.i;
+        }
+    __syncthreads();  // sv / si are free for the next transform
+}
+
+template <int N1>
+__global__ __launch_bounds__(ACQ_FUSED_THREADS, 2) void acq_inv_fused_kernel(AcqFftPlan plan, AcqFusedArgs g)
+{
+    constexpr int N2 = 1000, ROUNDS = (N1 + ACQ_FUSED_RPR - 1) / ACQ_FUSED_RPR;
+    extern __shared__ float2 sm[];
+    float2* W0 = sm;
+    float2* W1 = sm + ACQ_FUSED_RPR * N2;
+    float* svs = reinterpret_cast<float*>(sm + 2 * ACQ_FUSED_RPR * N2);
+    const int t = threadIdx.x;
+    const int N = plan.N;
+    const bool act = t < ACQ_FUSED_RPR * 100;
+    const int i = act ? t / 100 : 0, u = t - 100 * i;
+    // Blocks with equal blockIdx % 8 share an XCD (an L2) and start together; a cell re-reads 400 KB of spectra, so WHICH cells run
+    // side by side on an XCD decides whether those reads hit its 4 MB L2.  With >= 8 satellites XCD x owns satellites x, x + 8, ...
+    // (n_own of them) and its workgroups form a (satellite, lane) grid: lane j of J walks bins j, j + J, ...; at any time the XCD
+    // holds n_own code spectra and J signal spectra (4 + 8 of 200 KB each at 32 satellites), each shared by J resp. n_own
+    // workgroups.  With fewer satellites the roles swap: XCD x owns bins x, x + 8, ... and every satellite.  A work item is one
+    // transform; both transforms of a pair belong to one workgroup, in order.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const bool by_sat = g.n_sats >= 8;
+    const int n_own = by_sat ? (g.n_sats - xcd + 7) >> 3 : g.n_sats;   // satellites this XCD works on
+    const int n_walk = by_sat ? g.n_bins : (g.n_bins - xcd + 7) >> 3;  // bins every one of them is searched over here
+    const int J = n_own > 0 ? per_xcd / n_own : 0;                     // lanes per satellite
+    const int own = n_own > 0 ? slot % n_own : 0, lane_j = n_own > 0 ? slot / n_own : 0;
+    const int sat = by_sat ? xcd + 8 * own : own;
+    // items of this workgroup: (walk index w = lane_j, lane_j + J, ...) x (tr = 0 .. n_tr - 1)
+    const int items = (n_own > 0 && lane_j < J && lane_j < n_walk) ? ((n_walk - lane_j + J - 1) / J) * g.n_tr : 0;
+    float2 pa[10], pb[10];
+    auto rows_of = [&](int item, const float2*& ra, const float2*& rb, int& cell, int& tr) {
+        const int c = item / g.n_tr;
+        tr = item - c * g.n_tr;
+        const int w = lane_j + c * J;
+        const int bin = by_sat ? w : xcd + 8 * w;
+        cell = sat * g.n_bins + bin;
+        ra = g.A + (size_t)(tr * g.n_bins + bin) * N;
+        rb = g.B + (size_t)sat * N;
+    };
+    int item = 0;
+    const float2 *ra = nullptr, *rb = nullptr;
+    int cell = 0, tr = 0;
+    if (item < items)
+        {
+            rows_of(item, ra, rb, cell, tr);
+            if (act)
+                {
+#pragma unroll
+                    for (int j = 0; j < 10; j++) pa[j] = ra[(size_t)i * N2 + u + 100 * j];
+#pragma unroll
+                    for (int j = 0; j < 10; j++) pb[j] = rb[(size_t)i * N2 + u + 100 * j];
+                }
+        }
+    while (item < items)
+        {
+            // the item after this one (same cell's second transform, or the workgroup's next cell)
+            const int nitem = item + 1;
+            const float2 *na = ra, *nb = rb;
+            int ncell = cell, ntr = tr;
+            const bool have_next = nitem < items;
+            if (have_next) rows_of(nitem, na, nb, ncell, ntr);
+            FusedCols<N1> col;
+#define FUSED_ROUND(G)                                                                                                                       \
+    if (G < ROUNDS)                                                                                                                          \
+        acq_fused_round<N1, G>(plan, g, (G & 1) ? W1 : W0, (G & 1) ? W0 : W1, pa, pb, col,                                                   \
+            ra + (size_t)(G + 1) * ACQ_FUSED_RPR * N2, rb + (size_t)(G + 1) * ACQ_FUSED_RPR * N2, G + 1 < ROUNDS, t);                    \
+    __builtin_amdgcn_sched_barrier(0)
+            FUSED_ROUND(0);
+            FUSED_ROUND(1);
+            FUSED_ROUND(2);
+            FUSED_ROUND(3);
+            FUSED_ROUND(4);
+#undef FUSED_ROUND
+            const bool acc = (tr > 0) || (g.accumulate != 0);
+            const float2* nxa = have_next ? na + (size_t)i * N2 + u : nullptr;
+            const float2* nxb = have_next ? nb + (size_t)i * N2 + u : nullptr;
+            if (acc)
+                acq_fused_epilogue<N1, true>(plan, g.mag, col, cell, t, svs, pa, pb, act ? nxa : nullptr, nxb);
+            else
+                acq_fused_epilogue<N1, false>(plan, g.mag, col, cell, t, svs, pa, pb, act ? nxa : nullptr, nxb);
+            item = nitem;
+            ra = na;
+            rb = nb;
+            cell = ncell;
+            tr = ntr;
+        }
+}
+
+bool acq_inv_fusable(const AcqFftPlan& plan)
+{
+    return plan.N1 == 25 && plan.N2 == 1000 && plan.n_fac == 3 && plan.fac[0] == 10 && plan.fac[1] == 10 && plan.fac[2] == 10 && acq_cols_blocks(plan) == 4;
+}
+
+hipError_t acq_launch_inv_fused(hipStream_t st, const AcqFftPlan& plan, int n_sats, int n_bins, int n_tr, bool accumulate, const float2* A, const float2* B,
+    const float2* wN2, const float2* wN, const AcqMagArgs& mag, int n_cus)
+{
+    if (!acq_inv_fusable(plan) || (n_tr != 1 && n_tr != 2)) return hipErrorInvalidValue;
+    AcqFusedArgs g;
+    std::memset(&g, 0, sizeof g);
+    g.A = A;
+    g.B = B;
+    g.wN2 = wN2;
+    g.wN = wN;
+    g.mag = mag;
+    g.n_sats = n_sats;
+    g.n_bins = n_bins;
+    g.n_tr = n_tr;
+    g.accumulate = accumulate ? 1 : 0;
+    g.n_cells = n_sats * n_bins;
+    const size_t lds = (size_t)2 * ACQ_FUSED_RPR * 1000 * sizeof(float2) + 2 * (ACQ_FUSED_THREADS / 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done)
+        {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&acq_inv_fused_kernel<25>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
+            attr_done = true;
+        }
+    // one workgroup per CU (its registers and LDS leave room for one), a multiple of 8 so that every XCD gets the same share;
+    // an XCD with fewer cells than workgroups leaves the surplus idle
+    int grid = (n_cus > 0 ? n_cus : 256) & ~7;
+    const int max_per_xcd = n_sats >= 8 ? ((n_sats + 7) / 8) * n_bins : n_sats * ((n_bins + 7) / 8);
+    if (grid / 8 > max_per_xcd) grid = 8 * max_per_xcd;
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL(acq_inv_fused_kernel<25>, dim3(grid), dim3(ACQ_FUSED_THREADS), lds, st, plan, g);
+    return hipGetLastError();
+}
+
 // Inverse row pass of one satellite batch and the two-dwell column pass of the PREVIOUS batch in one launch sized to the chip
 // (4 workgroups per CU): three of every four workgroups of an XCD walk the row groups, the fourth walks the column blocks.  The
 // row pass is bound by instruction issue and the LDS pipe and loses nothing with three workgroups per CU instead of four; the
@@ -1370,6 +1763,8 @@ __global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_cols_k
                 }
         }
 }
+
+#endif  // GNSSCORR_EXPERIMENTS
 
 // ---- permutation (gather): out[a*N2 + b] = in[a + N1*b] (* mul[...]) ----
 __global__ void acq_permute_kernel(const float2* __restrict__ in, const float2* __restrict__ mul,
@@ -1828,7 +2223,7 @@ hipError_t acq_launch_permute(hipStream_t st, const float2* in, const float2* mu
     const AcqFftPlan& plan, int n_valid, int n_arrays, size_t in_stride, size_t mul_stride, size_t out_stride)
 {
     static const bool plain = [] {
-        const char* e = std::getenv("GNSSCORR_ACQ_PERMUTE");
+        const char* e = gc_exp_env("GNSSCORR_ACQ_PERMUTE");
         return e && std::strcmp(e, "plain") == 0;
     }();
     const size_t lds = sizeof(float2) * ACQ_PERM_TB * (size_t)plan.N1;
@@ -1848,12 +2243,13 @@ hipError_t acq_launch_permute(hipStream_t st, const float2* in, const float2* mu
 static int acq_rows_order()
 {
     static const int row_order = [] {
-        const char* e = std::getenv("GNSSCORR_ACQ_ROW_ORDER");
+        const char* e = gc_exp_env("GNSSCORR_ACQ_ROW_ORDER");
         return e ? std::atoi(e) : 2;
     }();
     return row_order;
 }
 
+#ifdef GNSSCORR_EXPERIMENTS
 bool acq_rows_cols_fusable(const AcqFftPlan& plan)
 {
     int rpw, iters[ACQ_MAX_FACTORS];
@@ -1891,12 +2287,14 @@ hipError_t acq_launch_rows_cols(hipStream_t st, const AcqFftPlan& plan, int n_ce
     return hipGetLastError();
 }
 
+#endif  // GNSSCORR_EXPERIMENTS
+
 hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan, int n_cells,
     const float2* A, AcqCellMap mapA, const float2* B, AcqCellMap mapB,
     float2* Q, const float2* wN2, const float2* wN)
 {
     static const bool force_wg = [] {
-        const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
+        const char* e = gc_exp_env("GNSSCORR_ACQ_ROWS");
         return e && std::strcmp(e, "wg") == 0;
     }();
     AcqRows2Args g;
@@ -1932,28 +2330,32 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             AcqFftPlan plan_arg = plan;
             void* args[] = {&plan_arg, &g};
             static const bool no_pairs = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
+                const char* e = gc_exp_env("GNSSCORR_ACQ_ROWS");
                 return e && std::strcmp(e, "nopair") == 0;  // A/B knob: the plain packed kernel
             }();
             AcqRows2Fn fn = inverse ? entry->inv : entry->fwd;
             if (!no_pairs && entry->pair_fwd) fn = inverse ? entry->pair_inv : entry->pair_fwd;
             static const bool interleaved_pairs = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_ROWS");
+                const char* e = gc_exp_env("GNSSCORR_ACQ_ROWS");
                 return e && std::strcmp(e, "pair2p") == 0;  // A/B knob: the pair kernel with (re, im) packing
             }();
+#ifdef GNSSCORR_EXPERIMENTS
             if (interleaved_pairs && entry->pair_fwd)
                 fn = inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<true, 10, 10, 10>) : reinterpret_cast<AcqRows2Fn>(&acq_rows2p_kernel<false, 10, 10, 10>);
+#else
+            (void)interleaved_pairs;
+#endif
             // row order of the pair kernel: 0 = (bin, sat, k1), 1 = (bin, k1, sat), 2 = (k1, bin, sat) with the last digit running fastest.
             // An XCD walks a contiguous eighth of the rows; with 2 it needs row k1 of every spectrum and of every code at a time (a few
             // hundred KB, read once per launch), with 0 / 1 it sweeps all the codes once per bin and its L2 (4 MB) has dropped them by then.
             g.sat_fastest = (B != nullptr && g.n_sats > 1) ? acq_rows_order() : 0;
             static const int dbg = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_DBG");  // phase-elimination timing (ACQ_ROWS3_DBG builds only)
+                const char* e = gc_exp_env("GNSSCORR_ACQ_DBG");  // phase-elimination timing (ACQ_ROWS3_DBG builds only)
                 return e ? std::atoi(e) : 0;
             }();
             g.dbg = dbg;
             static const int persist = [] {
-                const char* e = std::getenv("GNSSCORR_ACQ_PERSIST");  // workgroups per CU of the persistent row launch (0: one block per group)
+                const char* e = gc_exp_env("GNSSCORR_ACQ_PERSIST");  // workgroups per CU of the persistent row launch (0: one block per group)
                 return e ? std::atoi(e) : 0;  // measured: with the (bin, k1, sat) order 4 per CU (what the LDS admits) was 2 % faster than a block per group,
                                               // with the (k1, bin, sat) order a block per group is 2-3 % faster (0.311-0.321 vs 0.320-0.327 ms per search)
             }();
@@ -1976,7 +2378,7 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
             if (ea != hipSuccess) return ea;
         }
     static const int row_threads = [] {
-        const char* e = std::getenv("GNSSCORR_ACQ_ROW_THREADS");
+        const char* e = gc_exp_env("GNSSCORR_ACQ_ROW_THREADS");
         int v = e ? std::atoi(e) : 0;
         return (v == 64 || v == 128 || v == 256) ? v : 0;
     }();

@@ -84,6 +84,10 @@ struct gc_acq
     // 0.31 ms per search: a column workgroup needs its CU-mates' loads in flight to hide its two load phases, and the row pass slows down
     // with fewer than three workgroups
     bool roles = false;
+    // Experiment, off by default ($GNSSCORR_ACQ_ONCHIP=1, experiments build): N = 25 x 1000 plans run the inverse transform of a cell
+    // entirely on its CU (acq_inv_fused_kernel, no inter-pass buffer).  Measured 0.525 ms per cfg4 search against 0.311 ms for the
+    // two-pass form: DESIGN.md section 3.2
+    bool onchip = false;
     hipStream_t side = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
     size_t q_stride = 0;      // float2 elements between the two halves of d_Q (0: single buffer)
@@ -257,10 +261,15 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
     ACQ_TRY(hipMalloc(&a->d_codes, (size_t)n_sats * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_xw, (size_t)a->n_bins_alloc * N * sizeof(float2)));
     ACQ_TRY(hipMalloc(&a->d_X, (size_t)2 * a->n_bins_alloc * N * sizeof(float2)));  // two dwells' spectra (see inv_pending)
-    if (const char* e = std::getenv("GNSSCORR_ACQ_FUSE")) a->fuse_dwells = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GNSSCORR_ACQ_OVERLAP")) a->overlap = std::atoi(e) != 0;
-    if (const char* e = std::getenv("GNSSCORR_ACQ_ROLES")) a->roles = std::atoi(e) != 0;
+    if (const char* e = gc_exp_env("GNSSCORR_ACQ_FUSE")) a->fuse_dwells = std::atoi(e) != 0;
+    if (const char* e = gc_exp_env("GNSSCORR_ACQ_OVERLAP")) a->overlap = std::atoi(e) != 0;
+    if (const char* e = gc_exp_env("GNSSCORR_ACQ_ROLES")) a->roles = std::atoi(e) != 0;
+    if (const char* e = gc_exp_env("GNSSCORR_ACQ_ONCHIP")) a->onchip = std::atoi(e) != 0;
+#ifdef GNSSCORR_EXPERIMENTS
     a->roles = a->roles && a->fuse_dwells && acq_rows_cols_fusable(a->plan);
+#else
+    a->roles = a->overlap = a->onchip = false;
+#endif
     if (a->roles && n_sats > 1) a->q_stride = q_cells * N;  // second inter-pass buffer
     if (a->overlap && a->sats_per_batch < n_sats)
         {
@@ -469,7 +478,15 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
         m.tmp_bin = n_bins - 1;
         return m;
     };
-    if (pair && a->roles && a->q_stride != 0 && per_batch < a->n_sats && !a->overlap)
+#ifdef GNSSCORR_EXPERIMENTS
+    if (a->onchip && acq_inv_fusable(a->plan))
+        {
+            // N = 25 x 1000: the whole inverse transform of every cell in ONE launch that keeps a cell's values on the CU (no
+            // inter-pass buffer, no satellite batches); a pair's two transforms run back to back on the cell's workgroup
+            const AcqMagArgs m = mag_args(0);
+            e = acq_launch_inv_fused(st, a->plan, a->n_sats, n_bins, pair ? 2 : 1, accumulate, a->d_X, a->d_codes, a->d_wN2, a->d_wN, m, a->ctx->n_cus);
+        }
+    else if (pair && a->roles && a->q_stride != 0 && per_batch < a->n_sats && !a->overlap)
         {
             // rows(0); rows(b) + columns(b - 1) in one launch, b = 1 ..; columns(last)
             const int epi = accumulate ? ACQ_EPI_MAG2_ACC : ACQ_EPI_MAG2;
@@ -495,6 +512,7 @@ static hipError_t acq_inverse(gc_acq* a, hipStream_t st, bool pair, bool accumul
                 }
         }
     else
+#endif
     {
     const bool two_streams = a->overlap && a->q_stride != 0 && per_batch < a->n_sats;
     int b = 0;

@@ -60,6 +60,15 @@ gc_status gc_abi_check(size_t sizeof_epoch_params, size_t sizeof_loop_conf, size
     return GC_OK;
 }
 
+int gc_build_has_experiments(void)
+{
+#ifdef GNSSCORR_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int gc_device_count(void)
 {
     int n = 0;

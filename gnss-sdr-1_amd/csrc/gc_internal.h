@@ -9,6 +9,16 @@
 #include <cstdio>
 #include <mutex>
 
+// Experiment switches (measured-slower kernels and their tuning variables) exist only in builds made with
+// `make EXTRA=-DGNSSCORR_EXPERIMENTS`: the product library reads no tuning variable from the environment and carries none of those
+// kernels.  gc_build_has_experiments() (gnsscorr.h) tells a test which build it runs on.
+#include <cstdlib>
+#ifdef GNSSCORR_EXPERIMENTS
+static inline const char* gc_exp_env(const char* name) { return std::getenv(name); }
+#else
+static inline const char* gc_exp_env(const char*) { return nullptr; }
+#endif
+
 // thread-local last-error text (gc_last_error)
 void gc_set_error(const char* fmt, ...);
 gc_status gc_fail(gc_status st, const char* fmt, ...);

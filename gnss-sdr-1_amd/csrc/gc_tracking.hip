@@ -725,7 +725,7 @@ static gc_l1_batcher* l1_batcher_get(gc_ctx* ctx)
     L1Holder* h = new L1Holder();
     h->be.device = ctx->device;
     h->bat = new gc_l1_batcher(&h->be, (int)(sizeof(float2) * GC_MAX_TAPS));
-    if (const char* e = std::getenv("GNSSCORR_L1_SECOND_LANE")) h->bat->min_second_lane = std::max(1, std::atoi(e));
+    if (const char* e = gc_exp_env("GNSSCORR_L1_SECOND_LANE")) h->bat->min_second_lane = std::max(1, std::atoi(e));
     ctx->l1_batcher_free = &l1_batcher_free;
     ctx->l1_batcher.store(h, std::memory_order_release);
     return usable(h);
@@ -758,7 +758,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
         "correlator: code_length_chips %d not supported (max %d)", c->code_length_chips, kMaxLdsTableFloats / per_chip - 64);
     gc_device_guard g(c->ctx->device);
     static const bool batching = [] {
-        const char* e = std::getenv("GNSSCORR_L1_BATCH");  // 0: every call is its own launch under the context mutex (round-1 behaviour)
+        const char* e = gc_exp_env("GNSSCORR_L1_BATCH");  // 0: every call is its own launch under the context mutex (round-1 behaviour)
         return !(e && e[0] == '0');
     }();
     gc_l1_batcher* bat = (c->zero_copy && batching) ? l1_batcher_get(c->ctx) : nullptr;
@@ -806,7 +806,7 @@ static gc_status correlator_run(gc_correlator* c, int mode, float rem_carr, floa
     int chunks = (N + 1 + 511) / 512;
     int n_slices = chunks / 2;
     static const int one_wg_max = [] {
-        const char* e = std::getenv("GNSSCORR_L1_ONE_WG_MAX");  // tuning knob: windows up to this length run in one workgroup
+        const char* e = gc_exp_env("GNSSCORR_L1_ONE_WG_MAX");  // tuning knob: windows up to this length run in one workgroup
         return e ? std::atoi(e) : 2048;  // measured: beyond ~2000 samples several workgroups + the partial-sum launch win
     }();
     if (N <= one_wg_max) n_slices = 1;
@@ -901,7 +901,7 @@ gc_status gc_correlator_init(gc_correlator* c, int max_signal_length_samples, in
     GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), sizeof(gc_correlator::Staging), hipHostMallocMapped));
     GC_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_out), sizeof(float2) * GC_MAX_TAPS, hipHostMallocMapped));
     {
-        const char* e = std::getenv("GNSSCORR_L1_COPY");  // 1: stage the window in HBM with explicit copies instead
+        const char* e = gc_exp_env("GNSSCORR_L1_COPY");  // 1: stage the window in HBM with explicit copies instead
         c->zero_copy = !(e && e[0] == '1');
     }
     if (c->zero_copy)
@@ -1047,7 +1047,7 @@ gc_status gc_correlator_batch_stats(gc_ctx* ctx, uint64_t* n_batches, uint64_t* 
     if (void* p = ctx->l1_batcher.load(std::memory_order_acquire))
         {
             st = static_cast<L1Holder*>(p)->bat->stats();
-            if (const char* e = std::getenv("GNSSCORR_L1_TRACE"))
+            if (const char* e = gc_exp_env("GNSSCORR_L1_TRACE"))
                 if (e[0] == '1' && st.n_batches)
                     std::fprintf(stderr, "gnsscorr level-1 batcher: %llu batches, %llu calls; per batch: prepare %.1f us, launch %.1f us, wait %.1f us, scatter %.1f us; per call in the batcher %.1f us\n",
                         st.n_batches, st.n_requests, st.t_prep / st.n_batches, st.t_launch / st.n_batches, st.t_sync / st.n_batches, st.t_scatter / st.n_batches,

@@ -503,7 +503,15 @@ static __device__ __forceinline__ void trk_loop(const GC_GLOBAL typename IqFmt<F
 // With SC16 the returned pair holds the two 32-bit integer sums as bit patterns.
 // With DATA (pilot tracking) cd.code2 is the data component's replica: its prompt sum is returned to tid == NTAPS and the
 // window needs 2x the LDS floats.
+#ifdef GNSSCORR_EXPERIMENTS
 #include "trk_chips.hpp"
+#else
+// the chip-domain loop is compiled only into experiments builds; its names are declared so that the CHIPS = false instantiations parse
+#define TRK_SEG 512
+#define TRK_CHIPS_WAVE_FLOATS 0
+template <int NTAPS, bool WINDOWED, int THREADS, bool DATA, class B, class... A>
+static __device__ void trk_loop_chips(B, A...);
+#endif
 
 // CHIPS: the plain float loop summed per chip (trk_chips.hpp); the caller provides THREADS / 64 * TRK_CHIPS_WAVE_FLOATS more
 // floats of LDS behind the code window (rounded up to 16 bytes)

@@ -112,12 +112,13 @@ __global__ void trk_finish_kernel(const float2* __restrict__ partial, float2* __
 // -----------------------------------------------------------------------------
 // launcher
 // -----------------------------------------------------------------------------
-// $GNSSCORR_TRK_LOOP = samples | chips: which form of the plain float loop runs.  Default: samples -- the chip-domain form
-// (trk_chips.hpp) gives the same results and measured slower on MI355X in every mode of the bench (DESIGN.md section 3.1)
+// Experiments build only: $GNSSCORR_TRK_LOOP = samples | chips selects the form of the plain float loop.  The chip-domain form
+// (trk_chips.hpp) gives the same results and measured slower on MI355X in every mode of the bench (DESIGN.md appendix A)
+#ifdef GNSSCORR_EXPERIMENTS
 static bool trk_chip_domain()
 {
     static const bool on = [] {
-        const char* e = getenv("GNSSCORR_TRK_LOOP");
+        const char* e = gc_exp_env("GNSSCORR_TRK_LOOP");
         return e && e[0] == 'c';
     }();
     return on;
@@ -126,6 +127,7 @@ static size_t trk_chips_lds_bytes(int lds_table_floats)
 {
     return (size_t)(TRK_HDR_FLOATS + ((lds_table_floats + 3) & ~3) + TRK_THREADS / 64 * TRK_CHIPS_WAVE_FLOATS) * sizeof(float);
 }
+#endif
 template <int NTAPS, int FMT>
 static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStream_t st,
     const TrkChan* chans, const gc_epoch_params* params, float2* out, float2* partial,
@@ -134,12 +136,14 @@ static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStr
     switch (mode)
         {
         case TRK_MODE_PLAIN:
+#ifdef GNSSCORR_EXPERIMENTS
             if (FMT == GC_IQ_F32 && trk_chip_domain() && trk_chips_lds_bytes(lds_table_floats) <= 64 * 1024)
                 {
                     hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, GC_IQ_F32, false, false, true>), grid, dim3(TRK_THREADS),
                         trk_chips_lds_bytes(lds_table_floats), st, chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
                     break;
                 }
+#endif
             hipLaunchKernelGGL((trk_multicorrelator_kernel<NTAPS, false, false, FMT>), grid, dim3(TRK_THREADS), lds_bytes, st,
                 chans, params, out, partial, n_channels, n_epochs, n_slices, lds_table_floats, align_pairs);
             break;

@@ -156,6 +156,7 @@ API = {
     "gc_version": (C.c_char_p, []),
     "gc_abi_check": (C.c_int, [C.c_size_t] * 6),
     "gc_device_count": (C.c_int, []),
+    "gc_build_has_experiments": (C.c_int, []),
     "gc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "gc_ctx_destroy": (C.c_int, [_vp]),
     "gc_ctx_synchronize": (C.c_int, [_vp]),

@@ -62,6 +62,9 @@ gc_status gc_abi_check(size_t sizeof_epoch_params, size_t sizeof_loop_conf, size
     size_t sizeof_acq_conf, size_t sizeof_acq_result);
 /* Number of visible HIP devices (0 when none; never fails). */
 int gc_device_count(void);
+/* 1 when the library was built with -DGNSSCORR_EXPERIMENTS: it then also carries the measured-slower kernel variants and reads
+ * their GNSSCORR_* tuning variables.  The product build returns 0 and reads none of them. */
+int gc_build_has_experiments(void);
 
 /* ------------------------------------------------------------------------ */
 /* Context: one per GPU.  Owns a HIP stream and scratch buffers.             */
@@ -387,6 +390,11 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
 gc_status gc_trk_loop_stop(gc_trk_loop* l, int ch);
 /* n_epochs code periods of every channel in ONE launch.  dev_records: n_channels*n_epochs records,
  * channel-major.  The loop state persists on the device between calls. */
+/* Launch geometry of the engine, for tests and tuning (0 = automatic, the default): threads per workgroup (256, 512 or 1024) and
+ * workgroups per channel-period (1..16; the correlation of a period is cut into that many slices whose partial sums the last
+ * workgroup to finish adds in slice order before it runs the loop maths).  Records do not depend on the thread count beyond
+ * float rounding and are bit-identical for every slice count >= 2; see gc_trk_loop_run_dev. */
+gc_status gc_trk_loop_set_geometry(gc_trk_loop* l, int threads_per_workgroup, int slices_per_channel);
 gc_status gc_trk_loop_run_dev(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, void* stream);
 gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_records);
 

@@ -439,8 +439,7 @@ def _pairs_with_small_buffer_and_cshort_input(gctx, oracle, monkeypatch):
     c = _conf(fs, 1, 1, 4000.0, 2500, 500, max_dwells=3)
     monkeypatch.setenv("GNSSCORR_ACQ_Q_MB", "1")
     eng = []
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("GNSSCORR_ACQ_FUSE", fuse)
+    for _ in range(2):
         a = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
         a.set_input_format(gnsscorr.GC_IQ_I16)
         for s_, prn in enumerate(prns):
@@ -450,11 +449,16 @@ def _pairs_with_small_buffer_and_cshort_input(gctx, oracle, monkeypatch):
     st = torch.cuda.Stream()
     torch.cuda.synchronize()
     out = []
-    for a in eng:
+    for k_, a in enumerate(eng):
+        per_dwell = k_ == 1  # the second engine completes every dwell by itself (gc_acq_flush), as acquisition_core does
         a.reset()
         a.dwell_enqueue(d_x.data_ptr(), st.cuda_stream)
+        if per_dwell:
+            a.flush(st.cuda_stream)
         a.set_local_code(6, oracle.gps_l1_ca_code_sampled(31, fs))  # between the dwells of what would have been a pair
         a.dwell_enqueue(d_x.data_ptr() + 4 * n, st.cuda_stream)
+        if per_dwell:
+            a.flush(st.cuda_stream)
         a.dwell_enqueue(d_x.data_ptr() + 8 * n, st.cuda_stream)
         out.append(a.fetch_results(st.cuda_stream))
     for s_ in range(len(prns)):
@@ -469,8 +473,9 @@ def _pairs_with_small_buffer_and_cshort_input(gctx, oracle, monkeypatch):
 def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwells):
     """Dwells enqueued back to back are searched in pairs (the first of a pair is held back until the second arrives; an odd one
     and anything followed by a fetch run alone): 2 = one pair, 3 = pair + accumulating single, 4 = pair + accumulating pair,
-    5 = pair + pair + single.  An engine created with GNSSCORR_ACQ_FUSE=0 processes every dwell by itself, as acquisition_core does
-    (pcps_acquisition.cc:668-770): grids and results must be IDENTICAL, and the per-dwell engine is checked against the oracle."""
+    5 = pair + pair + single.  A second engine completes every dwell by itself (gc_acq_flush behind each one: inverse passes and
+    the statistics evaluation), as acquisition_core does (pcps_acquisition.cc:668-770, :747-755): grids and results must be
+    IDENTICAL, and the per-dwell engine is checked against the oracle."""
     import gnsscorr
     import torch
     from helpers import synth_stream
@@ -480,8 +485,7 @@ def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwe
     x, _ = synth_stream(chips, fs, n_dwells * n, seed=500 + n_dwells, cn0_db_hz=(40.0, 46.0), doppler_max=2000.0)
     c = _conf(fs, 1, 1, 4000.0, 2500, 500, max_dwells=n_dwells)
     engines = []
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("GNSSCORR_ACQ_FUSE", fuse)
+    for _ in range(2):
         a = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
         for s, prn in enumerate(prns):
             a.set_local_code(s, oracle.gps_l1_ca_code_sampled(prn, fs))
@@ -490,10 +494,12 @@ def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwe
     st = torch.cuda.Stream()
     torch.cuda.synchronize()
     res = []
-    for a in engines:
+    for k_, a in enumerate(engines):
         a.reset()
         for d in range(n_dwells):
             a.dwell_enqueue(d_x.data_ptr() + 8 * n * d, st.cuda_stream)
+            if k_ == 1:
+                a.flush(st.cuda_stream)  # per-dwell processing
         res.append(a.fetch_results(st.cuda_stream))
     for s, prn in enumerate(prns):
         g1, g0 = engines[0].grid(s), engines[1].grid(s)
@@ -522,44 +528,6 @@ def test_dwell_pairs_equal_per_dwell_processing(gctx, oracle, monkeypatch, n_dwe
     assert np.array_equal(a.grid(0), b.grid(0))
     for e in engines:
         e.close()
-
-
-def test_row_and_column_roles_in_one_launch(gctx, oracle, monkeypatch):
-    """GNSSCORR_ACQ_ROLES=1 (an experiment that measured slower and is off by default): the row pass of a
-    satellite batch and the two-dwell column pass of the previous batch as roles of one launch, two inter-pass buffers.  N = 25000
-    (the only plan it exists for), 6 satellites in 3 batches of pairs: grids and results must equal the separate launches' bit for bit."""
-    import gnsscorr
-    import torch
-    from helpers import synth_stream
-    fs, n = 25_000_000, 25000
-    prns = [1, 4, 9, 17, 22, 30]
-    chips = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in prns[:3]]
-    x, _ = synth_stream(chips, fs, 2 * n, seed=1234, cn0_db_hz=(44.0, 48.0), doppler_max=800.0)
-    c = _conf(fs, 1, 1, 25000.0, 1000, 250, max_dwells=2)  # 8 bins
-    monkeypatch.setenv("GNSSCORR_ACQ_Q_MB", "8")  # 8 bins x 200 KB = 1.6 MB per satellite and dwell: 2 satellites of a pair per batch
-    eng = []
-    for roles in ("1", "0"):
-        monkeypatch.setenv("GNSSCORR_ACQ_ROLES", roles)
-        a = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
-        for s_, prn in enumerate(prns):
-            a.set_local_code(s_, oracle.gps_l1_ca_code_sampled(prn, fs))
-        eng.append(a)
-    d_x = torch.from_numpy(x.view(np.float32)).cuda()
-    st = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    out = []
-    for a in eng:
-        a.reset()
-        a.dwell_enqueue(d_x.data_ptr(), st.cuda_stream)
-        a.dwell_enqueue(d_x.data_ptr() + 8 * n, st.cuda_stream)
-        out.append(a.fetch_results(st.cuda_stream))
-    for s_ in range(len(prns)):
-        assert np.array_equal(eng[0].grid(s_), eng[1].grid(s_)), s_
-        r1, r0 = out[0][s_], out[1][s_]
-        assert (r1.indext, r1.doppler_hz, r1.mag, r1.test_statistics, r1.second_peak) == (r0.indext, r0.doppler_hz, r0.mag, r0.test_statistics, r0.second_peak)
-    assert min(r.test_statistics for r in out[0][:3]) > max(r.test_statistics for r in out[0][3:])
-    for a in eng:
-        a.close()
 
 
 def test_gpu_grid_against_the_reference_matlab_analysis(gctx, oracle):

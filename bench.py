@@ -144,6 +144,49 @@ def cpu_baseline_threads(codes_np, shifts, sample_sig, sample_recs, budget_s, n_
     return n_threads * n_iter * N_EPOCH / dt / 1e6, n_threads * n_iter, dt
 
 
+def load_valu_ceilings():
+    """profiles/r03_valu_ceilings.json (profiles/tools/valu_ceiling.py): VALU-issue ceiling of each kernel's interior loop from its
+    disassembled instruction mix x the issue rates measured on the chip x 1024 SIMDs at the nominal clock."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_valu_ceilings.json")))["kernels"]
+    except Exception:
+        return {}
+
+
+def mode_roofline(ceil, parts, ms, serial_us_per_unit=None):
+    """Roofline of one bench entry that is not simply HBM-bound.  parts: [(samples, bytes_per_sample_from_hbm or 0, kernel key,
+    share of the chip's SIMDs the launch can use)]; the launches of an entry run back to back, so the entry's ceiling time is the sum
+    over parts of max(HBM time, VALU time) (+ a serial term for the closed loop).  Everything in Msamples/s so that the two bounds
+    are comparable; `bound` names the resource whose ceiling is lower."""
+    t_hbm = t_valu = t_bound = 0.0
+    n = 0
+    missing = False
+    for samples, bps, key, share in parts:
+        n += samples
+        th = samples * bps / (HBM_PEAK_GBPS * 1e9)
+        k = ceil.get(key)
+        if k is None:
+            missing = True
+            tv = 0.0
+        else:
+            tv = samples / (k["ceiling_msamples_s"] * 1e6 * share)
+        t_hbm += th
+        t_valu += tv
+        t_bound += max(th, tv)
+    if serial_us_per_unit:
+        t_bound += serial_us_per_unit * 1e-6
+    achieved = n / (ms * 1e-3) / 1e6
+    out = {"bound": "hbm" if t_hbm >= t_valu else "valu", "achieved": achieved, "unit": "Msamples/s",
+        "ceiling": n / t_bound / 1e6 if t_bound > 0 else None, "frac": t_bound / (ms * 1e-3),
+        "hbm_frac": t_hbm / (ms * 1e-3), "valu_frac": None if missing else t_valu / (ms * 1e-3),
+        "ceiling_source": "max(HBM: bytes / 8 TB/s, VALU: profiles/r03_valu_ceilings.json = interior-loop instruction mix (hipcc -S) x "
+                          "profiles/r02_valu_issue_rates.txt x 1024 SIMDs x 2.4 GHz) per launch, summed; counters: profiles/r03_trk_sq_counters.json"}
+    if serial_us_per_unit:
+        out["bound"] = out["bound"] + " + one-lane loop maths"
+        out["serial_us"] = serial_us_per_unit
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,6 +357,7 @@ def main():
     result = None
     if rank == 0:
         extra = {}
+        vceil = load_valu_ceilings()
         # the extras below are single-GPU side measurements: in a multi-GPU run the other ranks would only wait for them
         if world > 1:
             args.no_shared = True
@@ -333,7 +377,9 @@ def main():
             torch.cuda.synchronize()
             shared_ms = s0.elapsed_time(s1) / args.steps
             extra["shared_stream"] = {"value": samples_per_step / (shared_ms * 1e-3) / 1e6, "unit": "Msamples/s",
-                "ms_per_step": shared_ms, "note": "32 channels read one RF stream; input served from L2/Infinity Cache"}
+                "ms_per_step": shared_ms, "note": "32 channels read one RF stream; input served from L2/Infinity Cache",
+                # one stream of E x 25000 samples comes from HBM once; the other 31 reads are cache hits
+                "roofline": mode_roofline(vceil, [(samples_per_step, 8.0 / N_CHANNELS, "gps_l1_3tap_f32", 1.0)], shared_ms)}
         extra["realtime_factor_256ch"] = value / world / (256 * FS / 1e6)
 
         # ---- int16 IQ in HBM (cshort front-end samples, converted on load): 4 B per channel-sample ----
@@ -359,7 +405,8 @@ def main():
             i16_ms = i0.elapsed_time(i1) / args.steps
             extra["int16_input"] = {"value": samples_per_step / (i16_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": i16_ms,
                 "hbm_gbps": 4.0 * samples_per_step / (i16_ms * 1e-3) / 1e9,
-                "note": "same workload with lv_16sc_t IQ in HBM (distinct buffer per channel), 4 B per channel-sample"}
+                "note": "same workload with lv_16sc_t IQ in HBM (distinct buffer per channel), 4 B per channel-sample",
+                "roofline": mode_roofline(vceil, [(samples_per_step, 4.0, "gps_l1_3tap_i16", 1.0)], i16_ms)}
             b16.close()
             del q_streams
 
@@ -393,7 +440,8 @@ def main():
             gal_samples = N_CHANNELS * e_gal * n_gal
             extra["galileo_e1_5tap"] = {"value": gal_samples / (gal_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": gal_ms,
                 "hbm_gbps": 8.0 * gal_samples / (gal_ms * 1e-3) / 1e9,
-                "note": "32 channels, 25 Msps, 5 taps, L = 8184, N = 100000 (4 ms), distinct IQ buffer per channel"}
+                "note": "32 channels, 25 Msps, 5 taps, L = 8184, N = 100000 (4 ms), distinct IQ buffer per channel",
+                "roofline": mode_roofline(vceil, [(gal_samples, 8.0, "galileo_5tap_f32", 1.0)], gal_ms)}
             bg.close()
 
         # ---- BASELINE configs[4] per-GPU share: 32 channels = 16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I ----
@@ -431,7 +479,9 @@ def main():
             extra["hybrid_gps_galileo_beidou"] = {"value": hyb_samples / (hyb_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": hyb_ms,
                 "hbm_gbps": 8.0 * hyb_samples / (hyb_ms * 1e-3) / 1e9, "realtime_factor_32ch": hyb_samples / (hyb_ms * 1e-3) / (32 * FS),
                 "note": "one GPU's share of the 256-channel hybrid: 16 GPS L1 C/A (3 taps) + 8 Galileo E1 (5 taps, L = 8184, 4 ms) + 8 BeiDou B1I "
-                        "(3 taps, L = 2046), 25 Msps, distinct IQ buffer per channel, three launches per step"}
+                        "(3 taps, L = 2046), 25 Msps, distinct IQ buffer per channel, three launches per step",
+                "roofline": mode_roofline(vceil, [(hb[0][4], 8.0, "gps_l1_3tap_f32", 1.0), (hb[1][4], 8.0, "galileo_5tap_f32", 1.0),
+                    (hb[2][4], 8.0, "gps_l1_3tap_f32", 1.0)], hyb_ms)}
             for g in hb:
                 g[0].close()
 
@@ -510,7 +560,11 @@ def main():
             assert np.all(recs["valid"][:, :e_cl - 2] == 1)
             extra["closed_loop"] = {"channels": n_cl, "epochs": e_cl, "ms": cl_ms, "realtime_factor": e_cl * 1.0 / cl_ms,
                 "value": n_cl * e_cl * N_EPOCH / (cl_ms * 1e-3) / 1e6, "unit": "Msamples/s",
-                "note": "256 channels tracked in closed loop (DLL/PLL maths on the device), one workgroup per channel, shared RF stream"}
+                "note": "256 channels tracked in closed loop (DLL/PLL maths on the device), one workgroup per channel, shared RF stream",
+                # per code period: the correlation at the VALU ceiling of the CUs in use (one per channel) + 2.6 us of loop maths, records
+                # and barriers on one lane (measured with the correlation stubbed out), for e_cl periods in a row
+                "roofline": mode_roofline(vceil, [(n_cl * e_cl * N_EPOCH, 8.0 / n_cl, "closed_loop_3tap_512", min(1.0, n_cl / 256.0))], cl_ms,
+                    serial_us_per_unit=2.6 * e_cl)}
             loop.close()
 
             # Galileo E1 closed loop, 5 taps, 4 ms periods, data component alone vs pilot tracking (E1-C drives the loop,
@@ -546,7 +600,67 @@ def main():
                 gl.close()
             extra["closed_loop_galileo_e1"] = {"channels": n_g, "periods": e_g, "ms_data_only": gres[False], "ms_pilot": gres[True],
                 "realtime_factor_pilot": e_g * 4.0 / gres[True], "value": n_g * e_g * n_len / (gres[True] * 1e-3) / 1e6, "unit": "Msamples/s",
-                "note": "128 channels x 5 taps x 100000-sample periods in closed loop on a shared stream; pilot = 5 taps + the data component's prompt"}
+                "note": "128 channels x 5 taps x 100000-sample periods in closed loop on a shared stream; pilot = 5 taps + the data component's prompt",
+                "roofline": mode_roofline(vceil, [(n_g * e_g * n_len, 8.0 / n_g, "closed_loop_5tap_512_pilot", min(1.0, n_g / 256.0))], gres[True],
+                    serial_us_per_unit=2.6 * e_g)}
+
+        # ---- closed loop, one GPU's share of BASELINE configs[4]: 16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I in three
+        # engines on three streams ----
+        if not args.no_shared:
+            ms_total = min(E, 64)
+            rng_c = np.random.Generator(np.random.PCG64(1005))
+            side = [torch.cuda.Stream(device=dev) for _ in range(3)]
+            def make_engines(slices):
+                out = []
+                specs = [(16, CODE_LEN, 1, 0, 1.023e6, N_EPOCH, 0.001, 0.5, 0.0, 1), (8, 8184, 2, 1, 1.023e6, 4 * N_EPOCH, 0.004, 0.15, 0.6, 4),
+                    (8, 2046, 1, 0, 2.046e6, N_EPOCH, 0.001, 0.5, 0.0, 1)]
+                for n_c, L, spc, veml, chip_rate, vlen, period, el, vel, ms_per in specs:
+                    eng = gnsscorr.TrackingLoop(ctx, n_c, L)
+                    eng.set_geometry(slices_per_channel=slices)
+                    cfgc = gnsscorr.LoopConf()
+                    for k_, v_ in dict(fs_in=float(FS), signal_carrier_freq_hz=1575.42e6, code_chip_rate_hz=chip_rate, code_period_s=period, carrier_lock_th=0.85,
+                            code_length_chips=L // spc, code_samples_per_chip=spc, vector_length=vlen, pull_in_time_s=2, veml=veml, pll_filter_order=3,
+                            dll_filter_order=2, cn0_samples=20, cn0_min=25, max_lock_fail=50, pll_bw_hz=40.0, dll_bw_hz=2.0, fll_bw_hz=35.0,
+                            early_late_space_chips=el, very_early_late_space_chips=vel, acq_delay_samples=0.0, acq_doppler_hz=1000.0).items():
+                        setattr(cfgc, k_, v_)
+                    cd = codes[0] if L == CODE_LEN else np.sign(rng_c.standard_normal(L)).astype(np.float32)
+                    n_per = ms_total // ms_per
+                    recs_d = torch.zeros(n_c * n_per * gnsscorr.LOOP_RECORD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+                    out.append((eng, cfgc, cd, n_c, n_per, recs_d))
+                return out
+            def share_run(engs):
+                for k_, (eng, cfgc, cd, n_c, n_per, recs_d) in enumerate(engs):
+                    for ch in range(n_c):
+                        eng.set_input_dev(ch, streams[(k_ * 8 + ch) % N_CHANNELS].data_ptr(), n_stream)
+                        eng.start(ch, cfgc, cd)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for k_, (eng, cfgc, cd, n_c, n_per, recs_d) in enumerate(engs):
+                    eng.run_dev(n_per, recs_d.data_ptr(), side[k_].cuda_stream)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) * 1e3
+            engs = make_engines(0)
+            share_run(engs)
+            share_ms = min(share_run(engs) for _ in range(3))
+            for g_ in engs:
+                g_[0].close()
+            # floor of one millisecond of signal: the three engines run side by side, each needs its periods one after the other
+            def period_floor_us(key, n_samp):
+                k_ = vceil.get(key)
+                return (n_samp / (k_["ceiling_msamples_s"] * 1e6 / 256.0) * 1e6 + 2.6) if k_ else None
+            fl = [period_floor_us("closed_loop_3tap_1024", N_EPOCH), period_floor_us("closed_loop_5tap_512", 4 * N_EPOCH), period_floor_us("closed_loop_3tap_1024", N_EPOCH)]
+            share_roof = None
+            if all(f is not None for f in fl):
+                floor_us_per_ms = max(fl[0], fl[1] / 4.0, fl[2])
+                share_roof = {"bound": "valu + one-lane loop maths", "achieved": ms_total / share_ms, "ceiling": 1000.0 / floor_us_per_ms, "unit": "x real time",
+                    "frac": (1000.0 / floor_us_per_ms and (ms_total / share_ms) / (1000.0 / floor_us_per_ms)),
+                    "ceiling_source": "per code period: samples / (VALU ceiling of one CU, profiles/r03_valu_ceilings.json) + 2.6 us of one-lane loop maths; "
+                                      "the slowest of the three concurrent engines sets the floor"}
+            extra["closed_loop_cfg5_share"] = {"channels": 32, "ms_of_signal": ms_total, "ms": share_ms, "realtime_factor": ms_total / share_ms, "roofline": share_roof,
+                "note": "16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I channels x 25 Msps in closed loop, three engines on three "
+                        "streams, one 1024-thread workgroup per channel, host wall time of the three run_dev calls (launch-inclusive).  A code "
+                        "period costs ~11 us whatever the channel count (7.5 correlation by one CU + 2.6 one-lane loop maths): cutting periods "
+                        "into slices over more CUs was built and measured slower (13.4 us: experiments build, DESIGN.md appendix A)"}
 
         # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----
         if not args.no_acq:

@@ -622,6 +622,66 @@ static __device__ __forceinline__ void loop_after_correlation(LoopChan& s, const
     rec->current_prn_length_samples = s.current_prn_length_samples;
 }
 
+// What general_work does BEFORE the correlation of a code period (:1552-1600, :886-897), by one lane: end of the pull-in
+// transitory, the pull-in sample skip (state 1 -> 2), the decision whether a whole block is available below `limit`, and the
+// correlator's scalars narrowed to float exactly where do_correlation_step narrows them.  Returns 0 (and writes the period's
+// invalid record) when there is nothing to correlate: standby, or the input is exhausted.
+template <bool HD>
+static __device__ __forceinline__ int loop_prepare(LoopChan& s, unsigned long long limit, gc_epoch_params& s_p, gc_loop_record* rec)
+{
+    const gc_loop_conf& c = s.conf;
+    int go = 1;
+    if (s.pull_in_transitory)
+        {
+            if (c.pull_in_time_s < (s.sample_counter - s.acq_sample_stamp) / (unsigned long long)(int)c.fs_in) s.pull_in_transitory = 0;
+        }
+    if (s.state == 1)
+        {
+            // pull-in (:1568-1600): skip samples until the incoming code is aligned with the replica
+            const long long acq_trk_diff_samples = (long long)s.sample_counter - (long long)s.acq_sample_stamp;
+            const double delta = (double)acq_trk_diff_samples - s.acq_code_phase_samples;
+            s.code_freq_chips = c.code_chip_rate_hz;
+            s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+            const double T_prn_mod_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
+            s.acq_code_phase_samples = T_prn_mod_samples - fmod(delta, T_prn_mod_samples);
+            s.current_prn_length_samples = (int)round(T_prn_mod_samples);
+            const int samples_offset = (int)round(s.acq_code_phase_samples);
+            s.acc_carrier_phase_rad -= s.carrier_phase_step_rad * (double)samples_offset;
+            s.state = 2;
+            s.sample_counter += samples_offset;
+            s.pos += samples_offset;
+        }
+    if (s.state < 2 || s.pos + c.vector_length > limit) go = 0;  // standby, or the input block is exhausted
+    if (go)
+        {
+            // do_correlation_step (:886-897): the scalars are narrowed to float exactly there
+            const float spc = (float)c.code_samples_per_chip;
+            const float rem_carr = s.rem_carr_phase_rad;
+            const float pstep = (float)s.carrier_phase_step_rad;
+            s_p.sample_offset = s.pos;
+            s_p.phase0_re = cosf(rem_carr);
+            s_p.phase0_im = -sinf(rem_carr);
+            s_p.phase_inc_re = cosf(pstep);
+            s_p.phase_inc_im = -sinf(pstep);
+            const float prate = HD ? (float)s.carrier_phase_rate_step_rad : 0.0f;
+            s_p.phase_rate_re = cosf(prate);
+            s_p.phase_rate_im = -sinf(prate);
+            s_p.rem_code_phase_chips = (float)s.rem_code_phase_chips * spc;
+            s_p.code_phase_step_chips = (float)s.code_phase_step_chips * spc;
+            s_p.code_phase_rate_step_chips = HD ? (float)s.code_phase_rate_step_chips * spc : 0.0f;
+            s_p.n_samples = (int)c.vector_length;
+        }
+    else
+        {
+            // nothing to correlate: an invalid record marks the epoch (records are written in place, field by field: no stack copies)
+            unsigned* w = reinterpret_cast<unsigned*>(rec);
+            for (unsigned i = 0; i < sizeof(gc_loop_record) / 4; i++) w[i] = 0u;
+            rec->state = s.state;
+            rec->sample_counter = s.sample_counter;
+        }
+    return go;
+}
+
 // THREADS per channel: 1024 when there are few channels (one workgroup per CU), 256 when there are many
 // DATA: pilot tracking, every channel carries the data component's replica (chan.code2)
 // HD:   Dll_Pll_Conf::high_dyn -- the high-dynamics resampler and rotator (carrier and code rate terms)
@@ -661,57 +721,7 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
             gc_loop_record* rec = &recs[(size_t)ch * n_epochs + e];
             if (tid == 0)
                 {
-                    const gc_loop_conf& c = s.conf;
-                    int go = 1;
-                    if (s.pull_in_transitory)
-                        {
-                            if (c.pull_in_time_s < (s.sample_counter - s.acq_sample_stamp) / (unsigned long long)(int)c.fs_in) s.pull_in_transitory = 0;
-                        }
-                    if (s.state == 1)
-                        {
-                            // pull-in (:1568-1600): skip samples until the incoming code is aligned with the replica
-                            const long long acq_trk_diff_samples = (long long)s.sample_counter - (long long)s.acq_sample_stamp;
-                            const double delta = (double)acq_trk_diff_samples - s.acq_code_phase_samples;
-                            s.code_freq_chips = c.code_chip_rate_hz;
-                            s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
-                            const double T_prn_mod_samples = (1.0 / s.code_freq_chips) * (double)c.code_length_chips * c.fs_in;
-                            s.acq_code_phase_samples = T_prn_mod_samples - fmod(delta, T_prn_mod_samples);
-                            s.current_prn_length_samples = (int)round(T_prn_mod_samples);
-                            const int samples_offset = (int)round(s.acq_code_phase_samples);
-                            s.acc_carrier_phase_rad -= s.carrier_phase_step_rad * (double)samples_offset;
-                            s.state = 2;
-                            s.sample_counter += samples_offset;
-                            s.pos += samples_offset;
-                        }
-                    if (s.state < 2 || s.pos + c.vector_length > limit) go = 0;  // standby, or the input block is exhausted
-                    if (go)
-                        {
-                            // do_correlation_step (:886-897): the scalars are narrowed to float exactly there
-                            const float spc = (float)c.code_samples_per_chip;
-                            const float rem_carr = s.rem_carr_phase_rad;
-                            const float pstep = (float)s.carrier_phase_step_rad;
-                            s_p.sample_offset = s.pos;
-                            s_p.phase0_re = cosf(rem_carr);
-                            s_p.phase0_im = -sinf(rem_carr);
-                            s_p.phase_inc_re = cosf(pstep);
-                            s_p.phase_inc_im = -sinf(pstep);
-                            const float prate = HD ? (float)s.carrier_phase_rate_step_rad : 0.0f;
-                            s_p.phase_rate_re = cosf(prate);
-                            s_p.phase_rate_im = -sinf(prate);
-                            s_p.rem_code_phase_chips = (float)s.rem_code_phase_chips * spc;
-                            s_p.code_phase_step_chips = (float)s.code_phase_step_chips * spc;
-                            s_p.code_phase_rate_step_chips = HD ? (float)s.code_phase_rate_step_chips * spc : 0.0f;
-                            s_p.n_samples = (int)c.vector_length;
-                        }
-                    else
-                        {
-                            // nothing to correlate: an invalid record marks the epoch (records are written in
-                            // place, field by field: no stack copies)
-                            unsigned* w = reinterpret_cast<unsigned*>(rec);
-                            for (unsigned i = 0; i < sizeof(gc_loop_record) / 4; i++) w[i] = 0u;
-                            rec->state = s.state;
-                            rec->sample_counter = s.sample_counter;
-                        }
+                    const int go = loop_prepare<HD>(s, limit, s_p, rec);
                     s_go = go;
                 }
             __syncthreads();
@@ -731,6 +741,181 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
         for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += THREADS) dst[i] = src[i];
     }
 }
+
+#ifdef GNSSCORR_EXPERIMENTS
+// -----------------------------------------------------------------------------
+// Few channels on a big chip (the sharded receiver: 32 channels per GPU, BASELINE configs[4]): one workgroup per channel leaves
+// 7 of 8 CUs idle and a code period costs its full 10 us whatever the load.  Here a channel-period is cut into S slices, one
+// workgroup each (the batched kernel's slicing: trk_epoch's `slice` of `n_slices`), ONE launch per code period: a slice leaves
+// its partial sums in global memory and draws a ticket; the workgroup that draws the last one adds the partials IN SLICE ORDER
+// (deterministic: no float atomics), runs the period's scalar loop maths on one lane exactly as the persistent kernel does
+// (loop_after_correlation), prepares the NEXT period's correlator scalars (loop_prepare) and writes the state back.  The kernel
+// boundary is the only grid-wide synchronisation: no spinning, no co-residency assumption.  Records agree with the persistent
+// kernel's to float rounding (the sums are associated differently); for a given slice count they are reproducible bit for bit.
+// MEASURED SLOWER than the persistent kernel and therefore an experiments-build option only (gc_trk_loop_set_geometry refuses
+// slices > 1 in the product library): 32 channels x 25 Msps, 13.4 us per code period with 4 or 8 slices (15.3 with 2, 16.4 with
+// 16) against 11.4 us for one 1024-thread workgroup per channel -- of the launch's 12 us only ~2 are the slice's correlation; the
+// rest is a chain of dependent round trips the persistent kernel does not have (descriptor and scalars from the previous launch,
+// code window, first samples, write-through of the partials, ticket, state in, state out) around the same 2.6 us of one-lane maths.
+// -----------------------------------------------------------------------------
+// Hand-off of the partial sums: every byte is stored with sc1 (agent-scope relaxed atomic stores: write-through), the storing lane
+// drains them (s_waitcnt vmcnt(0)) and then adds to the channel's ticket counter; the lane whose add returns S - 1 reads them with
+// sc1 loads, which bypass its CU's L1.  That is the fence-free form MI355X_MICROARCH.md lists as measured valid on gfx950 (one
+// storing lane per workgroup, the last adder told by the value its add returned); LOOP_SLICE_FENCES=1 adds the agent-scope
+// release / acquire pair of acq_final_kernel around it (~3.4 us per period on the critical path).
+#ifndef LOOP_SLICE_FENCES
+#define LOOP_SLICE_FENCES 0
+#endif
+struct LoopPrep
+{
+    gc_epoch_params p;
+    int go;
+    int pad;
+};
+
+// the correlator scalars of the first period of a launch sequence (and its invalid record when there is nothing to correlate)
+template <bool HD>
+__global__ __launch_bounds__(64) void trk_loop_prepare_kernel(LoopChan* __restrict__ chans, LoopPrep* __restrict__ prep, gc_loop_record* __restrict__ recs, int n_epochs,
+    const unsigned long long* __restrict__ limits)
+{
+    __shared__ LoopChan s;
+    __shared__ gc_epoch_params s_p;
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&chans[ch]);
+        unsigned* dst = reinterpret_cast<unsigned*>(&s);
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (s.n_taps == 0) return;  // standby slot: the slice kernel writes its all-zero records
+    if (tid == 0)
+        {
+            const unsigned long long limit = limits ? limits[ch] : s.chan.n_iq;
+            const int go = loop_prepare<HD>(s, limit, s_p, &recs[(size_t)ch * n_epochs]);
+            prep[ch].p = s_p;
+            prep[ch].go = go;
+        }
+    __syncthreads();
+    {
+        unsigned* dst = reinterpret_cast<unsigned*>(&chans[ch]);
+        const unsigned* src = reinterpret_cast<const unsigned*>(&s);
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += 64) dst[i] = src[i];
+    }
+}
+
+// code period `e` of every channel: blockIdx -> (channel, slice) with all slices of a channel on one XCD (they share the window)
+template <int NTAPS, int THREADS, int FMT, bool DATA, bool HD>
+__global__ __launch_bounds__(THREADS) void trk_closed_loop_slice_kernel(LoopChan* __restrict__ chans, gc_loop_record* __restrict__ recs, int n_epochs, int e,
+    int n_channels, int n_slices, int lds_table_floats, const unsigned long long* __restrict__ limits, LoopPrep* __restrict__ prep, float2* __restrict__ partial,
+    unsigned* __restrict__ tickets)
+{
+    extern __shared__ float lds[];
+    __shared__ LoopChan s;  // the finishing workgroup's copy of the channel state (the others use .chan and .n_taps only)
+    __shared__ gc_epoch_params s_p;
+    __shared__ float2 s_corr[GC_MAX_TAPS];
+    __shared__ int s_go, s_last;
+    const int tid = threadIdx.x;
+    // b = (group * n_slices + slice) * 8 + x, channel = group * 8 + x: equal b % 8 (one XCD under round-robin placement) for a channel's slices
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slice = q % n_slices, ch = (q / n_slices) * 8 + x;
+    if (ch >= n_channels) return;
+    constexpr int NOUT = NTAPS + (DATA ? 1 : 0);
+    gc_loop_record* rec = &recs[(size_t)ch * n_epochs + e];
+    if (tid == 0)
+        {
+            s.chan = chans[ch].chan;
+            s.n_taps = chans[ch].n_taps;
+            s_p = prep[ch].p;
+            s_go = prep[ch].go;
+        }
+    __syncthreads();
+    if (s.n_taps != NTAPS)
+        {
+            // a channel that has not been started (or was stopped): standby record, written by its first slice
+            if (slice == 0)
+                {
+                    unsigned* w = reinterpret_cast<unsigned*>(rec);
+                    for (unsigned i = tid; i < sizeof(gc_loop_record) / 4; i += THREADS) w[i] = 0u;
+                }
+            return;
+        }
+    if (s_go)
+        {
+            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA, LOOP_PF, false, LOOP_NT != 0, LOOP_WHOLE != 0>(s.chan, s_p, slice, n_slices, lds_table_floats, lds, LOOP_ALIGN_PAIRS);
+            if (tid < NOUT) s_corr[tid] = r;
+        }
+    __syncthreads();
+    if (tid == 0)
+        {
+            // hand the partial sums over; the workgroup that draws the last ticket finishes the period (all in one lane:
+            // stores -> release fence -> ticket, ticket -> acquire fence -> loads; the same protocol as acq_final_kernel)
+            float* pv = reinterpret_cast<float*>(partial + ((size_t)ch * n_slices + slice) * GC_MAX_TAPS);
+            if (s_go)
+                for (int t = 0; t < NOUT; t++)
+                    {
+                        __hip_atomic_store(pv + 2 * t, s_corr[t].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pv + 2 * t + 1, s_corr[t].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#if LOOP_SLICE_FENCES
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sc1 (write-through) stores above have left for L2 / memory
+            const unsigned ticket = __hip_atomic_fetch_add(tickets + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (ticket == (unsigned)n_slices - 1u) ? 1 : 0;
+#if LOOP_SLICE_FENCES
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last slice to finish: the rest of general_work for this period ----
+    // (the channel state and prep[] were written by the PREVIOUS launch: visible across the kernel boundary to plain loads)
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(&chans[ch]);
+        unsigned* dst = reinterpret_cast<unsigned*>(&s);
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid == 0)
+        {
+            const unsigned long long limit = limits ? limits[ch] : s.chan.n_iq;
+            if (s_go)
+                {
+                    float2 taps[GC_MAX_TAPS];
+                    for (int t = 0; t < NOUT; t++) taps[t] = make_float2(0.f, 0.f);
+                    for (int sl = 0; sl < n_slices; sl++)  // slice order: the same sums whichever workgroup finishes last
+                        {
+                            const float* qv = reinterpret_cast<const float*>(partial + ((size_t)ch * n_slices + sl) * GC_MAX_TAPS);
+                            for (int t = 0; t < NOUT; t++)
+                                {
+                                    taps[t].x += __hip_atomic_load(qv + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    taps[t].y += __hip_atomic_load(qv + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                        }
+                    for (int t = 0; t < NOUT; t++) s_corr[t] = taps[t];
+                    loop_after_correlation<NTAPS, DATA>(s, s_corr, rec);
+                }
+            // the next period's scalars (a period that found nothing to correlate leaves the state where it was: the next one
+            // is decided again, as the persistent kernel decides every period)
+            if (e + 1 < n_epochs)
+                {
+                    const int go = loop_prepare<HD>(s, limit, s_p, rec + 1);
+                    prep[ch].p = s_p;
+                    prep[ch].go = go;
+                }
+            __hip_atomic_store(tickets + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+    __syncthreads();
+    {
+        unsigned* dst = reinterpret_cast<unsigned*>(&chans[ch]);
+        const unsigned* src = reinterpret_cast<const unsigned*>(&s);
+        for (unsigned i = tid; i < sizeof(LoopChan) / 4; i += THREADS) dst[i] = src[i];
+    }
+}
+
+#else
+struct LoopPrep;
+#endif  // GNSSCORR_EXPERIMENTS
 
 __global__ void trk_loop_start_kernel(LoopChan* chans, int ch)
 {
@@ -754,7 +939,12 @@ struct gc_trk_loop
     int high_dyn = 0;                         // high-dynamics mode of the started channels
     gc_loop_record* d_recs = nullptr;
     size_t recs_cap = 0;
-    int forced_threads = 0;  // $GNSSCORR_LOOP_THREADS (256 / 512 / 1024): tuning knob
+    int forced_threads = 0;  // gc_trk_loop_set_geometry: threads per workgroup of the persistent kernel (0: by channel count)
+    int forced_slices = 0;   // gc_trk_loop_set_geometry: workgroups per channel-period (0: by channel count; 1: persistent kernel)
+    LoopPrep* d_prep = nullptr;      // sliced launches: next period's correlator scalars per channel
+    float2* d_slice_partial = nullptr;
+    unsigned* d_tickets = nullptr;
+    int slice_cap = 0;               // slices the partial buffer was allocated for
     int iq_format = GC_IQ_F32;  // sample format of every channel's input (gc_trk_loop_set_input_format)
     std::vector<char> started;
     std::vector<const void*> iq;
@@ -811,11 +1001,6 @@ gc_status gc_trk_loop_create(gc_ctx* ctx, int n_channels, int max_code_length, g
     l->ctx_ref.bind(ctx);
     l->n_channels = n_channels;
     l->max_code_len = max_code_length;
-    if (const char* e = std::getenv("GNSSCORR_LOOP_THREADS"))
-        {
-            const int v = std::atoi(e);
-            if (v == 256 || v == 512 || v == 1024) l->forced_threads = v;
-        }
     hipError_t e1 = hipMalloc(&l->d_chans, sizeof(LoopChan) * n_channels);
     hipError_t e2 = hipMalloc(&l->d_codes, sizeof(float) * (size_t)n_channels * max_code_length);
     if (e1 != hipSuccess || e2 != hipSuccess)
@@ -861,10 +1046,29 @@ gc_status gc_trk_loop_destroy(gc_trk_loop* l)
     (void)hipFree(l->d_codes);
     (void)hipFree(l->d_data_codes);
     (void)hipFree(l->d_recs);
+    (void)hipFree(l->d_prep);
+    (void)hipFree(l->d_slice_partial);
+    (void)hipFree(l->d_tickets);
     loop_free_limits(l);
     for (gc_stream* r : l->streams)
         if (r) gc_stream_drop(r);
     delete l;
+    return GC_OK;
+}
+
+gc_status gc_trk_loop_set_geometry(gc_trk_loop* l, int threads_per_workgroup, int slices_per_channel)
+{
+    GC_REQUIRE(l, "gc_trk_loop_set_geometry: NULL handle");
+    GC_REQUIRE(threads_per_workgroup == 0 || threads_per_workgroup == 256 || threads_per_workgroup == 512 || threads_per_workgroup == 1024,
+        "gc_trk_loop_set_geometry: threads_per_workgroup must be 0 (automatic), 256, 512 or 1024");
+    GC_REQUIRE(slices_per_channel >= 0 && slices_per_channel <= 16, "gc_trk_loop_set_geometry: slices_per_channel must be in 0..16 (0: automatic)");
+#ifndef GNSSCORR_EXPERIMENTS
+    GC_REQUIRE(slices_per_channel <= 1, "gc_trk_loop_set_geometry: sliced code periods measured slower than one workgroup per channel and exist in "
+                                        "experiments builds only (make exp)");
+#endif
+    std::lock_guard<std::mutex> lk(l->ctx->mtx);
+    l->forced_threads = threads_per_workgroup;
+    l->forced_slices = slices_per_channel;
     return GC_OK;
 }
 
@@ -1091,6 +1295,52 @@ extern "C" gc_status gc_trk_loop_stop(gc_trk_loop* l, int ch)
     return GC_OK;
 }
 
+#ifdef GNSSCORR_EXPERIMENTS
+// one launch per code period: `n_epochs` launches of n_channels x n_slices workgroups behind one prepare launch
+template <int NT, int FM, bool DA, bool HD>
+static hipError_t loop_launch_slices_t(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, hipStream_t st, int n_slices, int lds_table_floats,
+    const unsigned long long* limits)
+{
+    constexpr int TH = 256;
+    const size_t lds_bytes = (size_t)(trk_hdr_floats(TH) + lds_table_floats) * sizeof(float);
+    if (lds_bytes > 48 * 1024)
+        {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_slice_kernel<NT, TH, FM, DA, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (ea != hipSuccess) return ea;
+        }
+    hipLaunchKernelGGL((trk_loop_prepare_kernel<HD>), dim3(l->n_channels), dim3(64), 0, st, l->d_chans, l->d_prep, dev_records, n_epochs, limits);
+    const unsigned grid = (unsigned)(((l->n_channels + 7) / 8) * n_slices * 8);
+    for (int e = 0; e < n_epochs; e++)
+        hipLaunchKernelGGL((trk_closed_loop_slice_kernel<NT, TH, FM, DA, HD>), dim3(grid), dim3(TH), lds_bytes, st, l->d_chans, dev_records, n_epochs, e, l->n_channels, n_slices,
+            lds_table_floats, limits, l->d_prep, l->d_slice_partial, l->d_tickets);
+    return hipGetLastError();
+}
+template <int NT, int FM>
+static hipError_t loop_launch_slices_f(gc_trk_loop* l, bool pilot, bool hd, int n_epochs, gc_loop_record* dev_records, hipStream_t st, int n_slices, int lds_table_floats,
+    const unsigned long long* limits)
+{
+    if (pilot) return hd ? loop_launch_slices_t<NT, FM, true, true>(l, n_epochs, dev_records, st, n_slices, lds_table_floats, limits)
+                         : loop_launch_slices_t<NT, FM, true, false>(l, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+    return hd ? loop_launch_slices_t<NT, FM, false, true>(l, n_epochs, dev_records, st, n_slices, lds_table_floats, limits)
+              : loop_launch_slices_t<NT, FM, false, false>(l, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+}
+static hipError_t loop_launch_slices(gc_trk_loop* l, bool pilot, int n_epochs, gc_loop_record* dev_records, hipStream_t st, int n_slices, int lds_table_floats,
+    const unsigned long long* limits)
+{
+    const bool hd = l->high_dyn != 0;
+    if (l->n_taps == 5)
+        {
+            if (l->iq_format == GC_IQ_I16) return loop_launch_slices_f<5, GC_IQ_I16>(l, pilot, hd, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+            if (l->iq_format == GC_IQ_I8) return loop_launch_slices_f<5, GC_IQ_I8>(l, pilot, hd, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+            return loop_launch_slices_f<5, GC_IQ_F32>(l, pilot, hd, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+        }
+    if (l->iq_format == GC_IQ_I16) return loop_launch_slices_f<3, GC_IQ_I16>(l, pilot, hd, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+    if (l->iq_format == GC_IQ_I8) return loop_launch_slices_f<3, GC_IQ_I8>(l, pilot, hd, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+    return loop_launch_slices_f<3, GC_IQ_F32>(l, pilot, hd, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+}
+
+#endif  // GNSSCORR_EXPERIMENTS
+
 extern "C" {
 
 static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, hipStream_t st, bool positions_known)
@@ -1191,6 +1441,36 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
     const int n_cus = l->ctx->n_cus > 0 ? l->ctx->n_cus : 256;
     const int threads = l->forced_threads ? l->forced_threads : (2 * l->n_channels <= n_cus ? 1024 : l->n_channels <= 2 * n_cus ? 512 : 256);
     const size_t lds_bytes = (size_t)(trk_hdr_floats(threads) + lds_table_floats) * sizeof(float);
+    // workgroups per channel-period: 1 = the persistent one-workgroup-per-channel kernel (always, in the product library); an
+    // experiments build cuts the period into slices on request (gc_trk_loop_set_geometry), one launch per period: measured slower
+    int n_slices = 1;
+#ifdef GNSSCORR_EXPERIMENTS
+    n_slices = std::max(1, l->forced_slices);
+    if (n_slices > 1)
+        {
+            if (!l->d_prep || n_slices > l->slice_cap)
+                {
+                    (void)hipFree(l->d_slice_partial);
+                    l->d_slice_partial = nullptr;
+                    if (!l->d_prep) LOOP_HIP_OR_CANCEL(hipMalloc(&l->d_prep, sizeof(LoopPrep) * l->n_channels));
+                    if (!l->d_tickets)
+                        {
+                            LOOP_HIP_OR_CANCEL(hipMalloc(&l->d_tickets, sizeof(unsigned) * l->n_channels));
+                            LOOP_HIP_OR_CANCEL(hipMemsetAsync(l->d_tickets, 0, sizeof(unsigned) * l->n_channels, st));
+                        }
+                    LOOP_HIP_OR_CANCEL(hipMalloc(&l->d_slice_partial, sizeof(float2) * GC_MAX_TAPS * (size_t)l->n_channels * n_slices));
+                    l->slice_cap = n_slices;
+                }
+            const hipError_t se = loop_launch_slices(l, pilot, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+            if (se != hipSuccess)
+                {
+                    cancel_all();
+                    return gc_fail(GC_ERR_HIP, "gc_trk_loop_run: kernel launch failed: %s", hipGetErrorString(se));
+                }
+        }
+#endif
+    if (n_slices <= 1)
+    {
 #define LAUNCH_LOOP_D(NT, TH, FM, DA)                                                                                                             \
     do                                                                                                                                        \
         {                                                                                                                                     \
@@ -1267,6 +1547,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
 #undef LAUNCH_LOOP_FMT
 #undef LAUNCH_LOOP
 #undef LAUNCH_LOOP_D
+    }
     {
         hipError_t le = hipGetLastError();
         if (le != hipSuccess)

@@ -212,6 +212,7 @@ API = {
     "gc_trk_loop_start": (C.c_int, [_vp, C.c_int, C.POINTER(LoopConf), _fp, C.c_int]),
     "gc_trk_loop_stop": (C.c_int, [_vp, C.c_int]),
     "gc_trk_loop_run_dev": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "gc_trk_loop_set_geometry": (C.c_int, [_vp, C.c_int, C.c_int]),
     "gc_trk_loop_run": (C.c_int, [_vp, C.c_int, _vp]),
     "gc_gps_l1_ca_code_gen_float": (C.c_int, [_fp, C.c_int32, C.c_uint32]),
     "gc_gps_l1_ca_code_gen_complex_sampled": (C.c_int, [_fp, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
@@ -771,6 +772,11 @@ class TrackingLoop:
 
     def stop(self, ch):
         _check(load_library().gc_trk_loop_stop(self._h, ch))
+
+    def set_geometry(self, threads_per_workgroup=0, slices_per_channel=0):
+        """0 = automatic.  threads: 256 / 512 / 1024 (persistent kernel); slices: workgroups per channel-period (1: persistent
+        one-workgroup-per-channel kernel; >= 2: one launch per code period, the last slice runs the loop maths)."""
+        _check(load_library().gc_trk_loop_set_geometry(self._h, int(threads_per_workgroup), int(slices_per_channel)))
 
     def run(self, n_epochs):
         """Returns a structured array [n_channels, n_epochs] of LOOP_RECORD_DTYPE."""

@@ -390,10 +390,10 @@ gc_status gc_trk_loop_start(gc_trk_loop* l, int ch, const gc_loop_conf* conf, co
 gc_status gc_trk_loop_stop(gc_trk_loop* l, int ch);
 /* n_epochs code periods of every channel in ONE launch.  dev_records: n_channels*n_epochs records,
  * channel-major.  The loop state persists on the device between calls. */
-/* Launch geometry of the engine, for tests and tuning (0 = automatic, the default): threads per workgroup (256, 512 or 1024) and
- * workgroups per channel-period (1..16; the correlation of a period is cut into that many slices whose partial sums the last
- * workgroup to finish adds in slice order before it runs the loop maths).  Records do not depend on the thread count beyond
- * float rounding and are bit-identical for every slice count >= 2; see gc_trk_loop_run_dev. */
+/* Launch geometry of the engine, for tests and tuning (0 = automatic, the default): threads per workgroup (256, 512 or 1024; the
+ * default follows the channel count) and workgroups per channel-period.  slices_per_channel > 1 (a period cut into slices, one launch
+ * per code period, the last slice to finish runs the loop maths) measured slower than one workgroup per channel (13.4 vs 11.4 us per
+ * period at 32 channels) and is accepted by experiments builds only; the product library takes 0 or 1. */
 gc_status gc_trk_loop_set_geometry(gc_trk_loop* l, int threads_per_workgroup, int slices_per_channel);
 gc_status gc_trk_loop_run_dev(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_records, void* stream);
 gc_status gc_trk_loop_run(gc_trk_loop* l, int n_epochs, gc_loop_record* host_records);

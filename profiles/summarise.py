@@ -12,8 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-PASSES = sys.argv[2:] or ["full", "trk", "acq", "sq"]
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+PASSES = sys.argv[2:] or ["line", "full", "trk", "trksq", "acq", "sq"]
 KERNEL = "trk_multicorrelator_kernel<3, false, false, 0, false, false, false>"
 
 
@@ -104,6 +104,10 @@ def acq_summary():
 def main():
     if "acq" in PASSES:
         acq_summary()
+    if "line" in PASSES:
+        for line in open(os.path.join(OUT, "bench_line.json")):
+            if line.startswith("{"):
+                open(os.path.join(PROF, TAG + "_bench_line.json"), "w").write(line)
     if "full" in PASSES:
         shutil.copy(find("prof_full", "kernel_stats.csv"), os.path.join(PROF, TAG + "_full_bench_kernel_stats.csv"))
         for line in open(os.path.join(OUT, "prof_full.log")):
@@ -111,10 +115,51 @@ def main():
                 open(os.path.join(PROF, TAG + "_bench_line_under_rocprof.json"), "w").write(line)
     if "trk" in PASSES:
         trk_summary()
+    if "trksq" in PASSES:
+        trk_sq_summary()
+
+
+def trk_sq_summary():
+    """SQ counters of every tracking kernel the bench line runs (one --pmc pass over bench.py with its extras), mean per launch."""
+    acc = {}
+    for r in csv.DictReader(open(find("prof_trk_sq", "counter_collection.csv"))):
+        n = short(r["Kernel_Name"])
+        if n.startswith("trk_"):
+            e = acc.setdefault(n, {}).setdefault(r["Counter_Name"], [0.0, 0])
+            e[0] += float(r["Counter_Value"])
+            e[1] += 1
+    out = {"round": int(TAG[1:3]), "command": "profiles/collect.sh pass trksq (bench.py --no-cpu --no-acq --preroll-ms 0 --segments 0 --steps 3)",
+        "units": "SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles (MI355X_MICROARCH.md); SQ_INSTS_* wave-instructions",
+        "kernels": {}}
+    for n, cs in sorted(acc.items()):
+        m = {c: v[0] / v[1] for c, v in sorted(cs.items())}
+        m["launches"] = max(v[1] for v in cs.values())
+        if m.get("SQ_WAVE_CYCLES"):
+            m["valu_active_share_of_wave_cycles"] = m.get("SQ_ACTIVE_INST_VALU", 0.0) / m["SQ_WAVE_CYCLES"]
+            m["wait_inst_share_of_wave_cycles"] = m.get("SQ_WAIT_INST_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
+            m["wait_any_share_of_wave_cycles"] = m.get("SQ_WAIT_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
+        if m.get("SQ_WAVES"):
+            m["valu_instructions_per_wave"] = m.get("SQ_INSTS_VALU", 0.0) / m["SQ_WAVES"]
+        out["kernels"][n] = m
+    json.dump(out, open(os.path.join(PROF, TAG + "_trk_sq_counters.json"), "w"), indent=1)
+    for n, m in out["kernels"].items():
+        print("%-90s VALU %.0f /wave, VALU-active %.2f, wait-inst %.2f, wait-any %.2f" % (n[:90], m.get("valu_instructions_per_wave", 0), m.get("valu_active_share_of_wave_cycles", 0),
+            m.get("wait_inst_share_of_wave_cycles", 0), m.get("wait_any_share_of_wave_cycles", 0)))
 
 
 def trk_summary():
     shutil.copy(find("prof_trk", "kernel_stats.csv"), os.path.join(PROF, TAG + "_tracking_kernel_stats.csv"))
+    # per-dispatch trace of the headline kernel (driver-shaped run: pre-roll, 5 warm-up, 20 timed, then the cold diagnostic pass): start
+    # relative to the first dispatch, duration and the gap to the previous one -- the evidence behind the start-of-load transient
+    rows = [r for r in csv.DictReader(open(find("prof_trk", "kernel_trace.csv"))) if r["Kernel_Name"].startswith("void " + KERNEL)]
+    with open(os.path.join(PROF, TAG + "_tracking_kernel_trace.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["dispatch", "start_us_since_first", "duration_us", "gap_to_previous_us"])
+        t0, prev_end = int(rows[0]["Start_Timestamp"]), None
+        for i, r in enumerate(rows):
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            w.writerow([i, "%.1f" % ((st - t0) / 1e3), "%.1f" % ((en - st) / 1e3), "%.1f" % (((st - prev_end) / 1e3) if prev_end else 0.0)])
+            prev_end = en
     fetch, nf = counter_mean(find("prof_fetch", "counter_collection.csv"), "FETCH_SIZE")
     write, nw = counter_mean(find("prof_write", "counter_collection.csv"), "WRITE_SIZE")
     for name, src in (("fetch", find("prof_fetch", "counter_collection.csv")), ("write", find("prof_write", "counter_collection.csv"))):

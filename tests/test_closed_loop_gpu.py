@@ -219,21 +219,14 @@ def test_closed_loop_workgroup_sizes_agree(gctx, oracle):
     conf = dict(GPS, acq_delay_samples=3100.0, acq_doppler_hz=-770.0, acq_samplestamp_samples=0, sample_counter=0)
     d = torch.from_numpy(x.view(np.float32)).cuda()
     recs = {}
-    old = os.environ.get("GNSSCORR_LOOP_THREADS")
-    try:
-        for threads in (1024, 512, 256):
-            os.environ["GNSSCORR_LOOP_THREADS"] = str(threads)
-            loop = gnsscorr.TrackingLoop(gctx, 2, 1023)
-            for ch in range(2):
-                loop.set_input_dev(ch, d.data_ptr(), x.size)
-                loop.start(ch, _conf(gnsscorr, **conf), code)
-            recs[threads] = loop.run(n_ep)
-            loop.close()
-    finally:
-        if old is None:
-            os.environ.pop("GNSSCORR_LOOP_THREADS", None)
-        else:
-            os.environ["GNSSCORR_LOOP_THREADS"] = old
+    for threads in (1024, 512, 256):
+        loop = gnsscorr.TrackingLoop(gctx, 2, 1023)
+        loop.set_geometry(threads_per_workgroup=threads, slices_per_channel=1)
+        for ch in range(2):
+            loop.set_input_dev(ch, d.data_ptr(), x.size)
+            loop.start(ch, _conf(gnsscorr, **conf), code)
+        recs[threads] = loop.run(n_ep)
+        loop.close()
     base = recs[1024]
     assert np.all(base["valid"] == 1) and np.array_equal(base[0], base[1])  # two channels on the same signal: identical
     for threads in (512, 256):

@@ -2,7 +2,8 @@
 built, held to the parity suite and measured slower than the product's, kept out of libgnsscorr.so:
   * the chip-domain form of the plain multicorrelator loop (csrc/trk_chips.hpp, GNSSCORR_TRK_LOOP=chips);
   * the inverse transform of a cell kept on its CU (acq_inv_fused_kernel, GNSSCORR_ACQ_ONCHIP=1);
-  * row and column passes as roles of one launch (GNSSCORR_ACQ_ROLES=1).
+  * row and column passes as roles of one launch (GNSSCORR_ACQ_ROLES=1);
+  * closed-loop code periods cut into slices, one launch per period (gc_trk_loop_set_geometry(slices > 1); tests/exp_sliced_loop.py).
 Opt-in: GNSSCORR_TEST_EXPERIMENTS=1 and the experiments library present; the default `-m gpu` run skips them (they re-run whole
 suites on slower kernels).  The switches are read once per process, hence the child interpreters."""
 import os
@@ -47,3 +48,7 @@ def test_acquisition_suite_with_the_on_chip_inverse_transform():
 def test_acquisition_suite_with_row_and_column_roles():
     _suite({"GNSSCORR_ACQ_ROLES": "1", "GNSSCORR_ACQ_Q_MB": "8"}, ["tests/test_acquisition_gpu.py::test_cfg4_full_width_32_prns_41_bins_2_dwells",
         "tests/test_acquisition_gpu.py::test_dwell_pairs_equal_per_dwell_processing"])
+
+
+def test_sliced_closed_loop_periods():
+    _suite({}, ["tests/exp_sliced_loop.py"])

@@ -601,7 +601,7 @@ def main():
             extra["closed_loop_galileo_e1"] = {"channels": n_g, "periods": e_g, "ms_data_only": gres[False], "ms_pilot": gres[True],
                 "realtime_factor_pilot": e_g * 4.0 / gres[True], "value": n_g * e_g * n_len / (gres[True] * 1e-3) / 1e6, "unit": "Msamples/s",
                 "note": "128 channels x 5 taps x 100000-sample periods in closed loop on a shared stream; pilot = 5 taps + the data component's prompt",
-                "roofline": mode_roofline(vceil, [(n_g * e_g * n_len, 8.0 / n_g, "closed_loop_5tap_512_pilot", min(1.0, n_g / 256.0))], gres[True],
+                "roofline": mode_roofline(vceil, [(n_g * e_g * n_len, 8.0 / n_g, "closed_loop_5tap_1024_pilot", min(1.0, n_g / 256.0))], gres[True],
                     serial_us_per_unit=2.6 * e_g)}
 
         # ---- closed loop, one GPU's share of BASELINE configs[4]: 16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I in three
@@ -648,7 +648,7 @@ def main():
             def period_floor_us(key, n_samp):
                 k_ = vceil.get(key)
                 return (n_samp / (k_["ceiling_msamples_s"] * 1e6 / 256.0) * 1e6 + 2.6) if k_ else None
-            fl = [period_floor_us("closed_loop_3tap_1024", N_EPOCH), period_floor_us("closed_loop_5tap_512", 4 * N_EPOCH), period_floor_us("closed_loop_3tap_1024", N_EPOCH)]
+            fl = [period_floor_us("closed_loop_3tap_1024", N_EPOCH), period_floor_us("closed_loop_5tap_1024", 4 * N_EPOCH), period_floor_us("closed_loop_3tap_1024", N_EPOCH)]
             share_roof = None
             if all(f is not None for f in fl):
                 floor_us_per_ms = max(fl[0], fl[1] / 4.0, fl[2])

@@ -45,6 +45,8 @@ KERNELS = {
     "closed_loop_3tap_512": ("trk_closed_loop.hip", "_Z22trk_closed_loop_kernelILi3ELi512ELi0ELb0ELb0EE", "dwordx4", 2),
     "closed_loop_5tap_512": ("trk_closed_loop.hip", "_Z22trk_closed_loop_kernelILi5ELi512ELi0ELb0ELb0EE", "dwordx4", 2),
     "closed_loop_5tap_512_pilot": ("trk_closed_loop.hip", "_Z22trk_closed_loop_kernelILi5ELi512ELi0ELb1ELb0EE", "dwordx4", 2),
+    "closed_loop_5tap_1024": ("trk_closed_loop.hip", "_Z22trk_closed_loop_kernelILi5ELi1024ELi0ELb0ELb0EE", "dwordx4", 2),
+    "closed_loop_5tap_1024_pilot": ("trk_closed_loop.hip", "_Z22trk_closed_loop_kernelILi5ELi1024ELi0ELb1ELb0EE", "dwordx4", 2),
 }
 
 

@@ -110,3 +110,17 @@ def test_loop_maths_against_reference_unit_test_vectors():
     subprocess.check_call(["make", "-s", "-C", d, "loop_maths_selftest"])
     p = subprocess.run([os.path.join(d, "loop_maths_selftest")], capture_output=True, text=True, timeout=60)
     assert p.returncode == 0 and "loop maths self-test passed" in p.stdout, p.stdout + p.stderr
+
+
+def test_product_library_carries_no_experiments():
+    """libgnsscorr.so is the product build: no measured-slower kernel variants, no tuning variables read from the environment
+    (those exist in libgnsscorr_exp.so only, `make exp`); a sliced closed-loop geometry is refused."""
+    import gnsscorr
+    L = gnsscorr.load_library()
+    assert L.gc_build_has_experiments() == 0
+    import subprocess
+    so = os.path.join(ROOT, "gnss-sdr-1_amd", "libgnsscorr.so")
+    strings = subprocess.run(["strings", so], capture_output=True, text=True).stdout
+    for name in ("GNSSCORR_TRK_LOOP", "GNSSCORR_ACQ_ROLES", "GNSSCORR_ACQ_ONCHIP", "GNSSCORR_ACQ_OVERLAP", "GNSSCORR_ACQ_DBG", "GNSSCORR_ACQ_PERSIST",
+            "GNSSCORR_L1_SECOND_LANE", "GNSSCORR_LOOP_THREADS", "acq_inv_fused_kernel", "acq_rows2p_kernel", "trk_closed_loop_slice_kernel"):
+        assert name not in strings, name

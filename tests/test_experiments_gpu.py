@@ -27,11 +27,6 @@ def _suite(env_extra, files):
     assert " passed" in r.stdout
 
 
-def test_product_library_has_no_experiments():
-    import gnsscorr
-    assert gnsscorr.load_library().gc_build_has_experiments() == 0
-
-
 def test_parity_suite_with_the_chip_domain_loop():
     """A complete second implementation of the hot loop with the reference's exact chip walk
     (volk_gnsssdr_32f_xn_resampler_32f_xn.h:77-94), held to the same parity suite."""

@@ -32,6 +32,11 @@ for p in (os.path.join(ROOT, "gnss-sdr-1_amd"), os.path.join(ROOT, "oracle")):
 
 import numpy as np
 
+# The HIP runtime maps streams onto 4 hardware queues by default; the three closed-loop engines of the cfg5 share then land two on one
+# queue and run one after the other (1.37 ms instead of 0.89 ms for 64 ms of signal, profiles/tools/loop_share_overlap.py).  Read by the
+# runtime when it initialises; named in the JSON line (`runtime_env`).  The single-stream measurements do not depend on it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 FS = 25_000_000
 N_EPOCH = 25000          # samples per code period at 25 Msps
 N_CHANNELS = 32          # per GPU
@@ -812,6 +817,7 @@ def main():
                         "start-of-load power transient (~8 ms); the timed region is unchanged: K full steps between barrier + synchronise. "
                         "--preroll-ms 0 removes it; roofline.cold_start_frac is the figure without it"},
             "cpu_baseline": cpu,
+            "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "per_gpu": [{k: g[k] for k in ("rank", "msamples_s", "hbm_frac", "kernel_ms", "steady_state_kernel_ms", "steady_state_hbm_frac", "cold_start_kernel_ms")} for g in per_gpu],
             "slowest_rank": max(per_gpu, key=lambda g: g["elapsed_s"])["rank"],
         }

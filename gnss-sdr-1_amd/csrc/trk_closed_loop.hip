@@ -687,7 +687,7 @@ static __device__ __forceinline__ int loop_prepare(LoopChan& s, unsigned long lo
 // HD:   Dll_Pll_Conf::high_dyn -- the high-dynamics resampler and rotator (carrier and code rate terms)
 template <int NTAPS, int THREADS, int FMT, bool DATA, bool HD = false>
 __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __restrict__ chans,
-    gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats, const unsigned long long* __restrict__ limits)
+    gc_loop_record* __restrict__ recs, int n_epochs, int lds_table_floats, const unsigned long long* __restrict__ limits, int resident)
 {
     extern __shared__ float lds[];
     __shared__ LoopChan s;
@@ -715,6 +715,14 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
         }
     // samples available to this launch: the channel's buffer length, or (ring input) the stream's head
     const unsigned long long limit = limits ? limits[ch] : s.chan.n_iq;
+    // The replica does not change during a launch and this workgroup has the CU's LDS to itself: the doubled image
+    // R[i] = code[i mod L] is loaded ONCE and every period addresses its window inside it, instead of re-reading the window from
+    // global memory period after period (one round trip and a barrier per period)
+    if (resident)
+        {
+            trk_fill_resident<THREADS>(lds, s.chan.code, DATA ? s.chan.code2 : nullptr, s.chan.code_len);
+            __syncthreads();
+        }
 
     for (int e = 0; e < n_epochs; e++)
         {
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(THREADS) void trk_closed_loop_kernel(LoopChan* __re
             __syncthreads();
             if (!s_go) continue;  // uniform: every later epoch of this launch is skipped the same way
 
-            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA, LOOP_PF, false, LOOP_NT != 0, LOOP_WHOLE != 0>(s.chan, s_p, 0, 1, lds_table_floats, lds, LOOP_ALIGN_PAIRS);
+            const float2 r = trk_epoch<NTAPS, HD, HD, FMT, false, false, THREADS, DATA, LOOP_PF, false, LOOP_NT != 0, LOOP_WHOLE != 0>(s.chan, s_p, 0, 1, lds_table_floats, lds, LOOP_ALIGN_PAIRS, resident != 0);
             if (tid < NTAPS + (DATA ? 1 : 0)) s_corr[tid] = r;
             __syncthreads();
 
@@ -1435,7 +1443,15 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
         }
     const unsigned long long* limits = any_ring ? l->d_limits[slot] : nullptr;
     const bool pilot = l->pilot > 0;
-    const int lds_table_floats = (l->max_code_len + 64) * (pilot ? 2 : 1);
+    // LDS code image: the doubled resident one (2 L + 64 floats per replica, loaded once per launch) when it fits beside the
+    // header, else the per-period window (L + 64)
+    int lds_table_floats = (2 * l->max_code_len + 64) * (pilot ? 2 : 1);
+    int resident = 1;
+    if ((size_t)(trk_hdr_floats(1024) + lds_table_floats) * sizeof(float) > 150 * 1024)
+        {
+            lds_table_floats = (l->max_code_len + 64) * (pilot ? 2 : 1);
+            resident = 0;
+        }
     // few channels: more threads each, so that a channel's epoch is spread over a whole CU (measured, 256 channels x 64
     // epochs on 256 CUs: 0.89 / 0.65 / 0.69 ms with 256 / 512 / 1024 threads)
     const int n_cus = l->ctx->n_cus > 0 ? l->ctx->n_cus : 256;
@@ -1461,7 +1477,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
                     LOOP_HIP_OR_CANCEL(hipMalloc(&l->d_slice_partial, sizeof(float2) * GC_MAX_TAPS * (size_t)l->n_channels * n_slices));
                     l->slice_cap = n_slices;
                 }
-            const hipError_t se = loop_launch_slices(l, pilot, n_epochs, dev_records, st, n_slices, lds_table_floats, limits);
+            const hipError_t se = loop_launch_slices(l, pilot, n_epochs, dev_records, st, n_slices, (l->max_code_len + 64) * (pilot ? 2 : 1), limits);
             if (se != hipSuccess)
                 {
                     cancel_all();
@@ -1478,7 +1494,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
                 LOOP_HIP_OR_CANCEL(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, TH, FM, DA>),                            \
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                                                             \
             hipLaunchKernelGGL((trk_closed_loop_kernel<NT, TH, FM, DA>), dim3(l->n_channels), dim3(TH), lds_bytes, st, l->d_chans, dev_records, \
-                n_epochs, lds_table_floats, limits);                                                                                          \
+                n_epochs, lds_table_floats, limits, resident);                                                                                          \
         }                                                                                                                                     \
     while (0)
 #define LAUNCH_LOOP(NT, TH, FM)                      \
@@ -1506,7 +1522,7 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
                 LOOP_HIP_OR_CANCEL(hipFuncSetAttribute(reinterpret_cast<const void*>(&trk_closed_loop_kernel<NT, 256, FM, DA, true>),                     \
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_hd));                                                          \
             hipLaunchKernelGGL((trk_closed_loop_kernel<NT, 256, FM, DA, true>), dim3(l->n_channels), dim3(256), lds_bytes_hd, st, l->d_chans,  \
-                dev_records, n_epochs, lds_table_floats, limits);                                                                             \
+                dev_records, n_epochs, lds_table_floats, limits, resident);                                                                             \
         }                                                                                                                                     \
     while (0)
 #define LAUNCH_LOOP_HD(NT, FM)                     \

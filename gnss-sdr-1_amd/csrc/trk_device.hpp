@@ -517,9 +517,32 @@ static __device__ void trk_loop_chips(B, A...);
 // floats of LDS behind the code window (rounded up to 16 bytes)
 // NT: nontemporal IQ loads -- for launches that stream every window once from HBM; off where many workgroups re-read one stream
 // from the caches over many epochs (the closed-loop kernel: 0.81 instead of 0.69 ms for 256 channels x 64 periods with the hint)
+// resident: the caller keeps R[i] = code[i mod L], i < 2 L + TRK_RESIDENT_PAD (and, with DATA, the data replica's image right behind
+// it) in the LDS table across calls -- the closed-loop kernel, one workgroup per channel for many code periods: nothing is filled
+// here, a window [lo, hi] of up to L + TRK_RESIDENT_PAD chips is addressed inside the doubled image, longer ones through the first L
+// entries with the modulo form.  Same chips, same sums as the filled window.
+#define TRK_RESIDENT_PAD 64
+static __device__ __forceinline__ int trk_resident_floats(int L) { return 2 * L + TRK_RESIDENT_PAD; }
+template <int THREADS>
+static __device__ __forceinline__ void trk_fill_resident(float* lds, const float* code, const float* code2, int L)
+{
+    float* table = lds + trk_hdr_floats(THREADS);
+    const GC_GLOBAL float* c = (const GC_GLOBAL float*)code;
+    const GC_GLOBAL float* c2 = (const GC_GLOBAL float*)code2;
+    const int n = trk_resident_floats(L);
+    for (int k = threadIdx.x; k < n; k += THREADS)
+        {
+            int i = k;
+            i = (i >= L) ? i - L : i;
+            i = (i >= L) ? i - L : i;
+            table[k] = c[i];
+            if (code2) table[n + k] = c2[i];
+        }
+}
+
 template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF, bool CHIPS = false, bool NT = (TRK_NT != 0), bool WHOLE = true>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
-    int lds_table_floats, float* lds, int align_pairs = TRK_ALIGN_PAIRS)
+    int lds_table_floats, float* lds, int align_pairs = TRK_ALIGN_PAIRS, bool resident = false)
 {
     // lds[0..HDRF): header (wave partials); then the code window
     static_assert(!CHIPS || (!HDR && !HDC && !CC && !SC16 && FMT == GC_IQ_F32), "the chip-domain loop exists for the plain float correlator");
@@ -656,14 +679,22 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
         }
     const long long span_ll = (long long)hi - (long long)lo + 1;
     typedef typename std::conditional<CC, f32x2, float>::type chip_t;
-    const bool windowed = monotone && span_ll > 0 && span_ll * (long long)(sizeof(chip_t) / sizeof(float)) * (DATA ? 2 : 1) <= (long long)lds_table_floats;
+    bool windowed = monotone && span_ll > 0 && span_ll * (long long)(sizeof(chip_t) / sizeof(float)) * (DATA ? 2 : 1) <= (long long)lds_table_floats;
     const GC_GLOBAL chip_t* code = (const GC_GLOBAL chip_t*)cd.code;
     chip_t* table_c = reinterpret_cast<chip_t*>(table);
     // data-component replica (pilot tracking): same layout, right behind the pilot's table
     constexpr int NACC = NTAPS + (DATA ? 1 : 0);
     float* table2 = DATA ? table + (windowed ? (int)span_ll : L) : nullptr;
     const GC_GLOBAL float* code2 = (const GC_GLOBAL float*)cd.code2;
-    if (windowed)
+    if (resident && !CC)
+        {
+            // the doubled image is in place: address the window inside it (chip - lo + cbase < 2 L + pad), or fall back to its
+            // first L entries with the modulo form
+            windowed = monotone && span_ll > 0 && span_ll <= (long long)L + TRK_RESIDENT_PAD;
+            if (windowed) lo -= posmod(lo, L);
+            if (DATA) table2 = table + trk_resident_floats(L);
+        }
+    else if (windowed)
         {
             const int span = (int)span_ll;
             const int cbase = posmod(lo, L);

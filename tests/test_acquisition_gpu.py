@@ -551,3 +551,44 @@ def test_gpu_grid_against_the_reference_matlab_analysis(gctx, oracle):
         n2 = float(acq.fft_size) ** 2
         assert abs(peak / n2 / a["maximum_correlation_peak"] - 1.0) < 3e-3 and abs(floor_ / n2 / a["noise_floor"] - 1.0) < 3e-3, (prn, peak / n2, floor_ / n2)
     acq.close()
+
+
+def test_flush_completes_held_back_work_without_a_fetch(gctx, oracle):
+    """gc_acq_flush (pcps_acquisition.cc:747-755 evaluates after every dwell): enqueues a held-back dwell's inverse passes and the
+    statistics kernel, copies nothing; idempotent; results after flush + fetch equal the results of a plain fetch; flushing an idle
+    engine is a no-op."""
+    import gnsscorr
+    import torch
+    from helpers import synth_stream
+    fs, n = 4_000_000, 4000
+    prns = [4, 8, 15]
+    chips = [oracle.gps_l1_ca_code(p).astype(np.float32) for p in prns[:2]]
+    x, _ = synth_stream(chips, fs, 2 * n, seed=77, cn0_db_hz=(44.0, 48.0), doppler_max=1500.0)
+    c = _conf(fs, 1, 1, 4000.0, 2500, 500, max_dwells=2)
+    d_x = torch.from_numpy(x.view(np.float32)).cuda()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    engines = []
+    for _ in range(2):
+        a = gnsscorr.PcpsAcquisition(gctx, len(prns), **c)
+        for s, prn in enumerate(prns):
+            a.set_local_code(s, oracle.gps_l1_ca_code_sampled(prn, fs))
+        engines.append(a)
+    a, b = engines
+    a.flush(st.cuda_stream)  # nothing pending
+    for e in engines:
+        e.reset()
+        e.dwell_enqueue(d_x.data_ptr(), st.cuda_stream)
+    a.flush(st.cuda_stream)
+    a.flush(st.cuda_stream)  # idempotent
+    ra, rb = a.fetch_results(st.cuda_stream), b.fetch_results(st.cuda_stream)
+    assert [(r.indext, r.doppler_hz, r.mag, r.test_statistics) for r in ra] == [(r.indext, r.doppler_hz, r.mag, r.test_statistics) for r in rb]
+    for e in engines:
+        e.dwell_enqueue(d_x.data_ptr() + 8 * n, st.cuda_stream)
+    a.flush(st.cuda_stream)
+    ra, rb = a.fetch_results(st.cuda_stream), b.fetch_results(st.cuda_stream)
+    for s in range(len(prns)):
+        assert np.array_equal(a.grid(s), b.grid(s))
+        assert (ra[s].indext, ra[s].mag, ra[s].test_statistics, ra[s].second_peak) == (rb[s].indext, rb[s].mag, rb[s].test_statistics, rb[s].second_peak)
+    for e in engines:
+        e.close()

@@ -368,3 +368,20 @@ def test_device_carrier_filter_against_the_pinned_filter(gctx, oracle, order, fl
             assert ulp == 0, (k, float(want), float(got))
         # keep the pinned filter on the device's trajectory: its state is a function of its inputs only, so nothing to re-seed
     assert worst <= (2 if (fll_pull_in or fll_steady) else 0), worst
+
+
+def test_product_library_refuses_sliced_periods(gctx):
+    """gc_trk_loop_set_geometry: thread counts are a product setting; slices > 1 (one launch per code period) measured slower and
+    exist in the experiments build only -- the product library says so instead of silently ignoring the request."""
+    import gnsscorr
+    if gnsscorr.load_library().gc_build_has_experiments():
+        pytest.skip("experiments build")
+    loop = gnsscorr.TrackingLoop(gctx, 2, 1023)
+    loop.set_geometry(threads_per_workgroup=512, slices_per_channel=1)
+    loop.set_geometry(0, 0)
+    with pytest.raises(Exception) as e:
+        loop.set_geometry(slices_per_channel=4)
+    assert "experiments" in str(e.value)
+    with pytest.raises(Exception):
+        loop.set_geometry(threads_per_workgroup=300)
+    loop.close()

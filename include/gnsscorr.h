@@ -530,7 +530,7 @@ gc_status gc_acq_dwell(gc_acq* a, const float* host_iq, gc_acq_result* host_resu
  * |.|^2 to the first; here both are added in one pass and the grid is written once): the inverse passes of a dwell with
  * dwell counter < max_dwells are held back until the next call on the handle -- an accumulating dwell joins it, anything else
  * (fetch, grid read, new code, reset ...) first completes it alone or, for a reset, discards it.  Results and grids are bit-identical
- * to per-dwell processing; $GNSSCORR_ACQ_FUSE=0 (read by gc_acq_create) turns the pairing off. */
+ * to per-dwell processing; a gc_acq_flush() behind every dwell gives per-dwell processing (the evaluation after every dwell of pcps_acquisition.cc:747-755). */
 gc_status gc_acq_dwell_enqueue(gc_acq* a, const void* dev_iq, void* stream);
 gc_status gc_acq_fetch_results(gc_acq* a, gc_acq_result* host_results, void* stream);
 /* Enqueues on `stream` whatever the enqueue-only calls have held back -- the inverse passes of a dwell waiting for a partner

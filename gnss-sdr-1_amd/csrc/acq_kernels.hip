@@ -1201,8 +1201,22 @@ static __device__ __forceinline__ void acq_cols_body(const AcqFftPlan& plan, con
     int xblk, int n_xblk, int cell, float* __restrict__ p1s, float* __restrict__ svs)
 {
     const int N2 = plan.N2, N = plan.N;
-    const int n2 = xblk * ACQ_THREADS + threadIdx.x;
-    const bool active = n2 < N2;
+    // Column of this thread.  The row-permuted epilogues (forward transforms) store natural index m = n2 + N2 k at (m % N1) N2 + m / N1:
+    // with consecutive columns on consecutive lanes every lane writes its 8 bytes N2 elements away from its neighbour's.  Where
+    // N2 is a multiple of N1 J (J = 256 / N1 columns groups per block) the block takes columns N1 j + r instead, lane = r J + j: then
+    // m % N1 = r and m / N1 = j + ..., so J consecutive lanes store J consecutive elements (80-byte runs at N1 = 25) -- 13.6 -> ~6 us
+    // for the 82 spectra of a dwell pair.  The loads of the inter-pass buffer become strided, but it was written just before and sits in L2.
+    constexpr bool PERM_EPI = (EPI == ACQ_EPI_PERM || EPI == ACQ_EPI_COMPLEX_CONJ_PERM);
+    constexpr int PJ = ACQ_THREADS / N1;
+    const bool perm_map = PERM_EPI && N1 > 1 && PJ >= 4 && (N2 % (N1 * PJ)) == 0 && n_xblk * (N1 * PJ) == N2;
+    int n2 = xblk * ACQ_THREADS + threadIdx.x;
+    bool active = n2 < N2;
+    if (perm_map)
+        {
+            const int t = threadIdx.x, r = t / PJ, j = t - r * PJ;
+            active = t < N1 * PJ;
+            n2 = active ? xblk * (N1 * PJ) + N1 * j + r : 0;
+        }
     float2 v0[N1], v1[N1];
     // ACQ_EPI_MAG2: the rows pass ran over 2 * n_bins "bins" per satellite, the second half being the next dwell's spectra
     constexpr bool PAIR = (EPI == ACQ_EPI_MAG2 || EPI == ACQ_EPI_MAG2_ACC);

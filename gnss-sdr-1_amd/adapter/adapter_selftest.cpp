@@ -385,6 +385,7 @@ static void test_glonass_acquisition(const std::string& dir)
     gnss_synchro.PRN = 2;
     blk->clear_events();
     acquisition.set_local_code();
+    EXPECT(blk->last_status() == GC_OK, "set_local_code with the FDMA offset: status %d: %s", blk->last_status(), gc_last_error());
     acquisition.set_state(1);
     run_flowgraph(acquisition, x, 2048);
     EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "channel -4: expected ACQ SUCCESS (%zu events)", blk->events().size());

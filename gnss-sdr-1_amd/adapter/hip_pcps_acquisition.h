@@ -160,7 +160,8 @@ public:
         if (d_acq != nullptr) d_status = gc_acq_set_frequency_offset(d_acq, d_old_freq);
         const size_t n = acq_parameters.bit_transition_flag ? d_fft_size / 2 : d_consumed_samples;
         d_code.assign(code, code + n);
-        if (d_acq != nullptr) d_status = gc_acq_set_local_code(d_acq, 0, reinterpret_cast<const float*>(d_code.data()));
+        // (a failed frequency-offset call must stay visible in last_status(): the search would run on the old wipe-off tables)
+        if (d_acq != nullptr && d_status == GC_OK) d_status = gc_acq_set_local_code(d_acq, 0, reinterpret_cast<const float*>(d_code.data()));
     }
 
     inline void set_active(bool active)

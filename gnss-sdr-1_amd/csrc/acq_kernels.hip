@@ -1854,25 +1854,27 @@ __global__ __launch_bounds__(256) void acq_permute_tiled_kernel(const float2* __
 
 // ---- Doppler wipe-off table (pcps_acquisition::update_local_carrier, :296-310) ----
 // volk_gnsssdr_s32f_sincos_32fc_generic: _phase += phase_inc in float32, out = (cosf, sinf)
-__global__ void acq_wipeoff_phase_kernel(const float* __restrict__ phase_inc, float* __restrict__ phase, int n_bins, int N)
+// The running phase is parked in the .x of the output element it belongs to and replaced by (cos, sin) in place: no scratch buffer
+// (the stream-ordered allocator this used to take one from is not something a set-up call of a library should depend on).
+__global__ void acq_wipeoff_phase_kernel(const float* __restrict__ phase_inc, float2* __restrict__ out, int n_bins, int N)
 {
     const int bin = blockIdx.x * blockDim.x + threadIdx.x;
     if (bin >= n_bins) return;
     const float inc = phase_inc[bin];
     float p = 0.0f;
-    float* row = phase + (size_t)bin * N;
+    float2* row = out + (size_t)bin * N;
     for (int i = 0; i < N; i++)
         {
-            row[i] = p;
+            row[i].x = p;
             p = p + inc;  // sequential float32 running sum, exactly as the reference
         }
 }
-__global__ void acq_wipeoff_sincos_kernel(const float* __restrict__ phase, float2* __restrict__ out, size_t total)
+__global__ void acq_wipeoff_sincos_kernel(float2* __restrict__ out, size_t total)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     float s, c;
-    sincosf(phase[i], &s, &c);
+    sincosf(out[i].x, &s, &c);
     out[i] = make_float2(c, s);
 }
 
@@ -2489,16 +2491,10 @@ hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const Acq
 
 hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float2* out, int n_bins, int N)
 {
-    // the float32 phase table reuses the output buffer's second half as scratch? no: separate pass
-    float* phase = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&phase), sizeof(float) * (size_t)n_bins * N, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(acq_wipeoff_phase_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, st, phase_inc, phase, n_bins, N);
+    hipLaunchKernelGGL(acq_wipeoff_phase_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, st, phase_inc, out, n_bins, N);
     size_t total = (size_t)n_bins * N;
-    hipLaunchKernelGGL(acq_wipeoff_sincos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, phase, out, total);
-    e = hipGetLastError();
-    hipError_t e2 = hipFreeAsync(phase, st);
-    return e != hipSuccess ? e : e2;
+    hipLaunchKernelGGL(acq_wipeoff_sincos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total);
+    return hipGetLastError();
 }
 
 hipError_t acq_launch_input_power(hipStream_t st, const float2* x, int n_valid, int N, float* out_power, float* tmp_all,

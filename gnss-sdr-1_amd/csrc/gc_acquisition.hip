@@ -389,9 +389,15 @@ gc_status gc_acq_set_frequency_offset(gc_acq* a, int64_t offset_hz)
     if (offset_hz == a->freq_offset_hz) return GC_OK;
     GC_HIP(acq_flush_inverse(a, a->ctx->stream));  // a held-back dwell was wiped off with the tables of its time
     GC_HIP(hipStreamSynchronize(a->ctx->stream));
+    const int64_t previous = a->freq_offset_hz;
     a->freq_offset_hz = offset_hz;
     hipError_t e = acq_build_main_wipeoffs(a, a->ctx->stream);
-    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_frequency_offset: %s", hipGetErrorString(e));
+    if (e != hipSuccess)
+        {
+            // the tables are in an unknown state: a repeated call with either offset must rebuild them
+            a->freq_offset_hz = previous == INT64_MIN ? INT64_MIN + 1 : INT64_MIN;
+            return gc_fail(GC_ERR_HIP, "gc_acq_set_frequency_offset: %s", hipGetErrorString(e));
+        }
     return GC_OK;
 }
 

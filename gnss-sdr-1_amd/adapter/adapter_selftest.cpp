@@ -50,6 +50,16 @@ static std::vector<gr_complex> read_iq(const std::string& path)
     return v;
 }
 
+// after a failed expectation on a search: the per-bin row maxima the statistics kernel scanned, so that the log names the bins
+template <class Block>
+static void dump_row_maxima(const Block& blk, const char* what, int doppler_max, int doppler_step)
+{
+    const auto rm = blk->row_maxima();
+    std::printf("  row maxima of the last search (%s), %zu bins: Doppler Hz / index / value\n", what, rm.size());
+    for (size_t d = 0; d < rm.size(); d++)
+        std::printf("   %6d %6u %.9g%s", -doppler_max + doppler_step * static_cast<int>(d), rm[d].second, rm[d].first, (d % 4 == 3 || d + 1 == rm.size()) ? "\n" : " |");
+}
+
 // feeds a capture to the block in scheduler-sized chunks until it reports an event
 // (repeat = file_source's repeat flag: the 2 ms capture is too short for a two-step search)
 template <class Adapter>
@@ -347,6 +357,7 @@ static void test_glonass_acquisition(const std::string& dir)
 {
     // real GLONASS L1 data: the NT1065 capture of glonass_l1_ca_dll_pll_tracking_test.cc, whose hard-coded hand-over is
     // delay 1343 samples / Doppler -2750 Hz for PRN 11 (frequency channel 0); slot 2 -> channel -4 in GLONASS_PRN
+    int fails_before = g_fail;
     auto x = read_iq(dir + "/kat_glonass_l1_nt1065_fs6625e6_4ms.bin");
     EXPECT(x.size() == 26499, "capture size %zu", x.size());
     x.resize(26500);
@@ -381,6 +392,8 @@ static void test_glonass_acquisition(const std::string& dir)
     EXPECT(std::abs(-2750.0 - gnss_synchro.Acq_doppler_hz) <= 250.0, "Doppler %g Hz", gnss_synchro.Acq_doppler_hz);
     std::printf("GLONASS L1 C/A acquisition (real capture, PRN 11 / channel 0): delay %g samples, Doppler %g Hz, statistic %g\n", gnss_synchro.Acq_delay_samples,
         gnss_synchro.Acq_doppler_hz, blk->test_statistics());
+    if (g_fail != fails_before) dump_row_maxima(blk, "channel 0", 10000, 250);
+    fails_before = g_fail;
     // slot 2 lives on frequency channel -4: the block installs DFRQ1_GLO * (-4) in set_local_code() and finds the satellite there
     gnss_synchro.PRN = 2;
     blk->clear_events();
@@ -390,8 +403,10 @@ static void test_glonass_acquisition(const std::string& dir)
     run_flowgraph(acquisition, x, 2048);
     EXPECT(blk->events().size() == 1 && blk->events()[0] == 1, "channel -4: expected ACQ SUCCESS (%zu events)", blk->events().size());
     EXPECT(std::abs(3000.0 - gnss_synchro.Acq_doppler_hz) <= 250.0, "channel -4 Doppler %g Hz", gnss_synchro.Acq_doppler_hz);
+    EXPECT(std::abs(502.0 - gnss_synchro.Acq_delay_samples) <= 1.0, "channel -4 delay %g samples", gnss_synchro.Acq_delay_samples);
     std::printf("GLONASS L1 C/A acquisition (slot 2 / channel -4, FDMA offset %d Hz): delay %g samples, Doppler %g Hz, statistic %g\n", -4 * 562500,
         gnss_synchro.Acq_delay_samples, gnss_synchro.Acq_doppler_hz, blk->test_statistics());
+    if (g_fail != fails_before) dump_row_maxima(blk, "channel -4", 10000, 250);
 }
 
 static void test_beidou_sizes()

@@ -425,6 +425,20 @@ public:
     uint64_t sample_counter() const { return d_sample_counter; }
     gc_status last_status() const { return d_status; }
 
+    //! per Doppler bin (maximum of the grid row, its index) of the last search as the engine's statistics kernel saw them: what a
+    //! failing test prints so that a red log names the bins (gc_acq_peek, GC_ACQ_PEEK_ROW_MAX)
+    std::vector<std::pair<float, uint32_t>> row_maxima() const
+    {
+        std::vector<std::pair<float, uint32_t>> out;
+        if (d_acq == nullptr) return out;
+        uint32_t fft = 0, cons = 0, bins = 0;
+        if (gc_acq_fft_size(d_acq, &fft, &cons, &bins) != GC_OK) return out;
+        std::vector<float> v(2 * static_cast<size_t>(bins));
+        if (gc_acq_peek(d_acq, GC_ACQ_PEEK_ROW_MAX, 0, v.data()) != GC_OK) return out;
+        for (uint32_t d = 0; d < bins; d++) out.emplace_back(v[2 * d], static_cast<uint32_t>(v[2 * d + 1]));
+        return out;
+    }
+
     //! name of the last file dump_results() wrote ("" if none)
     const std::string& last_dump_file() const { return d_last_dump_file; }
 

@@ -818,14 +818,34 @@ static __device__ __forceinline__ void pk_powers10(VC<V> w, VC<V>* tw)
 static __device__ __forceinline__ void lds_read_pairs10(const float* xr, const float* xi, PkC* a)
 {
     const unsigned ar = (unsigned)reinterpret_cast<uintptr_t>(xr), ai = (unsigned)reinterpret_cast<uintptr_t>(xi);  // low 32 bits of a flat LDS address = the LDS address
-#define RD(J) \
-    asm volatile("ds_read_b64 %0, %1 offset:" #J "*400" : "=v"(a[J].r) : "v"(ar)); \
-    asm volatile("ds_read_b64 %0, %1 offset:" #J "*400" : "=v"(a[J].i) : "v"(ai));
-    RD(0) RD(1) RD(2) RD(3) RD(4) RD(5) RD(6) RD(7) RD(8) RD(9)
-#undef RD
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0].r), "+v"(a[0].i), "+v"(a[1].r), "+v"(a[1].i), "+v"(a[2].r), "+v"(a[2].i), "+v"(a[3].r), "+v"(a[3].i), "+v"(a[4].r), "+v"(a[4].i),
-                   "+v"(a[5].r), "+v"(a[5].i), "+v"(a[6].r), "+v"(a[6].i), "+v"(a[7].r), "+v"(a[7].i), "+v"(a[8].r), "+v"(a[8].i), "+v"(a[9].r), "+v"(a[9].i));
+    // ONE statement: the twenty reads and their wait.  The compiler's own s_waitcnt insertion does not see LDS operations inside inline
+    // assembly, so nothing (a register copy, a spill of an output) may be scheduled between issue and wait; early-clobber outputs keep
+    // the address registers apart from the destinations
+    asm volatile(
+        "ds_read_b64 %0, %20 offset:0\n\t"
+        "ds_read_b64 %1, %21 offset:0\n\t"
+        "ds_read_b64 %2, %20 offset:400\n\t"
+        "ds_read_b64 %3, %21 offset:400\n\t"
+        "ds_read_b64 %4, %20 offset:800\n\t"
+        "ds_read_b64 %5, %21 offset:800\n\t"
+        "ds_read_b64 %6, %20 offset:1200\n\t"
+        "ds_read_b64 %7, %21 offset:1200\n\t"
+        "ds_read_b64 %8, %20 offset:1600\n\t"
+        "ds_read_b64 %9, %21 offset:1600\n\t"
+        "ds_read_b64 %10, %20 offset:2000\n\t"
+        "ds_read_b64 %11, %21 offset:2000\n\t"
+        "ds_read_b64 %12, %20 offset:2400\n\t"
+        "ds_read_b64 %13, %21 offset:2400\n\t"
+        "ds_read_b64 %14, %20 offset:2800\n\t"
+        "ds_read_b64 %15, %21 offset:2800\n\t"
+        "ds_read_b64 %16, %20 offset:3200\n\t"
+        "ds_read_b64 %17, %21 offset:3200\n\t"
+        "ds_read_b64 %18, %20 offset:3600\n\t"
+        "ds_read_b64 %19, %21 offset:3600\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a[0].r), "=&v"(a[0].i), "=&v"(a[1].r), "=&v"(a[1].i), "=&v"(a[2].r), "=&v"(a[2].i), "=&v"(a[3].r), "=&v"(a[3].i), "=&v"(a[4].r), "=&v"(a[4].i), "=&v"(a[5].r), "=&v"(a[5].i), "=&v"(a[6].r), "=&v"(a[6].i), "=&v"(a[7].r), "=&v"(a[7].i), "=&v"(a[8].r), "=&v"(a[8].i), "=&v"(a[9].r), "=&v"(a[9].i)
+        : "v"(ar), "v"(ai)
+        : "memory");
 }
 
 #ifndef ACQ_ROWS3_DBG
@@ -1854,28 +1874,54 @@ __global__ __launch_bounds__(256) void acq_permute_tiled_kernel(const float2* __
 
 // ---- Doppler wipe-off table (pcps_acquisition::update_local_carrier, :296-310) ----
 // volk_gnsssdr_s32f_sincos_32fc_generic: _phase += phase_inc in float32, out = (cosf, sinf)
-// The running phase is parked in the .x of the output element it belongs to and replaced by (cos, sin) in place: no scratch buffer
-// (the stream-ordered allocator this used to take one from is not something a set-up call of a library should depend on).
-__global__ void acq_wipeoff_phase_kernel(const float* __restrict__ phase_inc, float2* __restrict__ out, int n_bins, int N)
+// Two kernels, each writing a buffer it does not read: the running phases (one lane per bin: the float32 sum is sequential by
+// definition) go to a scratch array in natural order, then (cos, sin) of every phase is stored AT ITS ROW-PERMUTED POSITION
+// P[bin][a][b] = wipe[bin][a + N1 b] of the table the forward row pass reads.  (Rounds 1-3 built the table in natural order, permuted
+// it into a staging buffer and copied it back device-to-device; round 3 also parked the phases inside the table.  Nothing is built in
+// place any more and no copy engine takes part in a set-up call.)
+__global__ void acq_wipeoff_phase_kernel(const float* __restrict__ phase_inc, float* __restrict__ phase, int n_bins, int N)
 {
     const int bin = blockIdx.x * blockDim.x + threadIdx.x;
     if (bin >= n_bins) return;
     const float inc = phase_inc[bin];
     float p = 0.0f;
-    float2* row = out + (size_t)bin * N;
+    float* row = phase + (size_t)bin * N;
     for (int i = 0; i < N; i++)
         {
-            row[i].x = p;
+            row[i] = p;
             p = p + inc;  // sequential float32 running sum, exactly as the reference
         }
 }
-__global__ void acq_wipeoff_sincos_kernel(float2* __restrict__ out, size_t total)
+// one workgroup per (tile of 64 consecutive b, bin): reads the contiguous phases n = N1 b0 .. N1 (b0 + 64) - 1, stores 64-element
+// runs of each of the N1 permuted rows (the gather of acq_permute_tiled_kernel with sincosf on the way through LDS)
+__global__ __launch_bounds__(256) void acq_wipeoff_sincos_perm_kernel(const float* __restrict__ phase, float2* __restrict__ out, int N, int N1, int N2)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ float2 tile[];  // [ACQ_PERM_TB * N1]
+    const int bin = blockIdx.y;
+    const int b0 = blockIdx.x * ACQ_PERM_TB;
+    const int nb = min(ACQ_PERM_TB, N2 - b0);
+    const int base = N1 * b0, count = N1 * nb;
+    for (int i = threadIdx.x; i < count; i += 256)
+        {
+            float s, c;
+            sincosf(phase[(size_t)bin * N + base + i], &s, &c);
+            tile[i] = make_float2(c, s);
+        }
+    __syncthreads();
+    const int j = threadIdx.x & (ACQ_PERM_TB - 1);
+    for (int a = threadIdx.x / ACQ_PERM_TB; a < N1; a += 256 / ACQ_PERM_TB)
+        if (j < nb) out[(size_t)bin * N + (size_t)a * N2 + b0 + j] = tile[a + N1 * j];
+}
+// N1 too large for the tile: one thread per element, scattered 8-byte stores (set-up only)
+__global__ void acq_wipeoff_sincos_scatter_kernel(const float* __restrict__ phase, float2* __restrict__ out, int N, int N1, int N2, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    const size_t bin = i / (size_t)N;
+    const int n = (int)(i - bin * (size_t)N);
     float s, c;
-    sincosf(out[i].x, &s, &c);
-    out[i] = make_float2(c, s);
+    sincosf(phase[i], &s, &c);
+    out[bin * (size_t)N + (size_t)(n % N1) * N2 + n / N1] = make_float2(c, s);
 }
 
 // ---- integer input samples -> gr_complex (volk_gnsssdr_16ic_convert_32fc at the head of acquisition_core,
@@ -2489,11 +2535,24 @@ hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const Acq
         }
 }
 
-hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float2* out, int n_bins, int N)
+hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float* phase_scratch, float2* out, int n_bins, const AcqFftPlan& plan)
 {
-    hipLaunchKernelGGL(acq_wipeoff_phase_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, st, phase_inc, out, n_bins, N);
-    size_t total = (size_t)n_bins * N;
-    hipLaunchKernelGGL(acq_wipeoff_sincos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total);
+    const int N = plan.N;
+    hipLaunchKernelGGL(acq_wipeoff_phase_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, st, phase_inc, phase_scratch, n_bins, N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = sizeof(float2) * ACQ_PERM_TB * (size_t)plan.N1;
+    if (lds <= 48 * 1024)
+        {
+            dim3 grid((plan.N2 + ACQ_PERM_TB - 1) / ACQ_PERM_TB, n_bins);
+            hipLaunchKernelGGL(acq_wipeoff_sincos_perm_kernel, grid, dim3(256), lds, st, phase_scratch, out, N, plan.N1, plan.N2);
+        }
+    else
+        {
+            const size_t total = (size_t)n_bins * N;
+            hipLaunchKernelGGL(acq_wipeoff_sincos_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, phase_scratch, out, N, plan.N1,
+                plan.N2, total);
+        }
     return hipGetLastError();
 }
 

@@ -51,6 +51,10 @@ struct gc_acq
     unsigned* d_part_cnt = nullptr;   // and its ticket counters
     std::vector<char> code_set;
     int64_t freq_offset_hz = 0;  // d_old_freq: intermediate frequency / GLONASS FDMA channel offset
+    float* d_inc = nullptr;       // phase increments of the table being built [n_bins_alloc]
+    // the wipe-off tables hold what freq_offset_hz / the step-two centre say: cleared before a rebuild starts, set when it has
+    // completed; a search on tables in an unknown state is refused (GC_ERR_STATE) instead of run
+    bool wipe_valid = false, wipe2_valid = false;
     bool grid_logically_zero = true;  // gc_acq_reset() since the last dwell: the grid reads as zeros
     // The statistics of a dwell (acq_final_kernel) are computed when somebody can see them -- a fetch -- or when the next dwell
     // would not reproduce their side effect, not after every dwell: the reference evaluates the statistic after each dwell
@@ -119,6 +123,7 @@ static void acq_release(gc_acq* a)
     (void)hipFree(a->d_wN2);
     (void)hipFree(a->d_wipe_main);
     (void)hipFree(a->d_wipe2);
+    (void)hipFree(a->d_inc);
     (void)hipFree(a->d_codes);
     (void)hipFree(a->d_xw);
     (void)hipFree(a->d_X);
@@ -145,11 +150,15 @@ static void acq_release(gc_acq* a)
 // The wipe-off tables are kept in the row-permuted layout the forward row pass reads (P[bin][a][b] = wipe[bin][a + N1 * b]): the
 // product x * wipeoff[bin] (pcps_acquisition.cc:717) is then the two-operand load of that pass -- A = the table, B = the permuted
 // input block, shared by every bin -- instead of a kernel of its own that writes and re-reads n_bins x N products per dwell.
-static hipError_t acq_permute_wipe_table(gc_acq* a, float2* table, int n_bins, hipStream_t st)
+// A table is built out of place in two kernels (acq_launch_wipeoff): running phases into the inter-pass buffer d_Q (idle during a
+// set-up call: every caller has flushed the held-back passes), then (cos, sin) at the permuted positions of the table.  The caller
+// holds the context mutex.
+static hipError_t acq_build_wipeoffs(gc_acq* a, const std::vector<float>& inc, float2* table, hipStream_t st)
 {
-    const size_t N = a->fft_size;
-    hipError_t e = acq_launch_permute(st, table, nullptr, a->d_xw, a->plan, (int)N, n_bins, N, 0, N);
-    if (e == hipSuccess) e = hipMemcpyAsync(table, a->d_xw, (size_t)n_bins * N * sizeof(float2), hipMemcpyDeviceToDevice, st);
+    const int n = (int)inc.size();
+    hipError_t e = hipMemcpyAsync(a->d_inc, inc.data(), sizeof(float) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = acq_launch_wipeoff(st, a->d_inc, reinterpret_cast<float*>(a->d_Q), table, n, a->plan);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // `inc` may go out of scope; d_Q is free again
     return e;
 }
 
@@ -165,14 +174,9 @@ static hipError_t acq_build_main_wipeoffs(gc_acq* a, hipStream_t st)
             const float phase_step_rad = (float)(6.283185307179586 * freq / (float)a->conf.fs_in);
             inc[d] = -phase_step_rad;
         }
-    float* d_inc = nullptr;
-    hipError_t e = hipMalloc(&d_inc, sizeof(float) * a->n_bins_main);
-    if (e != hipSuccess) return e;
-    e = hipMemcpy(d_inc, inc.data(), sizeof(float) * a->n_bins_main, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe_main, (int)a->n_bins_main, (int)a->fft_size);
-    if (e == hipSuccess) e = acq_permute_wipe_table(a, a->d_wipe_main, (int)a->n_bins_main, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_inc);
+    a->wipe_valid = false;
+    const hipError_t e = acq_build_wipeoffs(a, inc, a->d_wipe_main, st);
+    a->wipe_valid = (e == hipSuccess);
     return e;
 }
 
@@ -283,6 +287,7 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
                 }
         }
     ACQ_TRY(hipMalloc(&a->d_Q, (a->q_stride ? 2 : 1) * q_cells * N * sizeof(float2)));
+    ACQ_TRY(hipMalloc(&a->d_inc, (size_t)a->n_bins_alloc * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_grid, (size_t)n_sats * a->n_bins_alloc * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_tmp, (size_t)n_sats * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_blkv, (size_t)n_sats * a->n_bins_alloc * a->n_blocks * sizeof(float)));
@@ -386,18 +391,13 @@ gc_status gc_acq_set_frequency_offset(gc_acq* a, int64_t offset_hz)
     GC_REQUIRE(a, "gc_acq_set_frequency_offset: NULL handle");
     gc_device_guard g(a->ctx->device);
     std::lock_guard<std::mutex> lk(a->ctx->mtx);
-    if (offset_hz == a->freq_offset_hz) return GC_OK;
+    if (offset_hz == a->freq_offset_hz && a->wipe_valid) return GC_OK;
     GC_HIP(acq_flush_inverse(a, a->ctx->stream));  // a held-back dwell was wiped off with the tables of its time
     GC_HIP(hipStreamSynchronize(a->ctx->stream));
-    const int64_t previous = a->freq_offset_hz;
     a->freq_offset_hz = offset_hz;
-    hipError_t e = acq_build_main_wipeoffs(a, a->ctx->stream);
-    if (e != hipSuccess)
-        {
-            // the tables are in an unknown state: a repeated call with either offset must rebuild them
-            a->freq_offset_hz = previous == INT64_MIN ? INT64_MIN + 1 : INT64_MIN;
-            return gc_fail(GC_ERR_HIP, "gc_acq_set_frequency_offset: %s", hipGetErrorString(e));
-        }
+    // a failed rebuild leaves wipe_valid clear: searches are refused until a later call (with any offset) has rebuilt the tables
+    const hipError_t e = acq_build_main_wipeoffs(a, a->ctx->stream);
+    if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_frequency_offset: %s", hipGetErrorString(e));
     return GC_OK;
 }
 
@@ -441,14 +441,10 @@ gc_status gc_acq_set_step_two(gc_acq* a, int enable, float doppler_center_hz)
             float phase_step_rad = (float)(6.283185307179586 * freq / (float)a->conf.fs_in);
             inc[d] = -phase_step_rad;
         }
-    float* d_inc = nullptr;
-    GC_HIP(hipMalloc(&d_inc, sizeof(float) * n2));
-    hipError_t e = hipMemcpy(d_inc, inc.data(), sizeof(float) * n2, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = acq_launch_wipeoff(st, d_inc, a->d_wipe2, (int)n2, (int)a->fft_size);
-    if (e == hipSuccess) e = acq_permute_wipe_table(a, a->d_wipe2, (int)n2, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_inc);
+    a->wipe2_valid = false;
+    const hipError_t e = acq_build_wipeoffs(a, inc, a->d_wipe2, st);
     if (e != hipSuccess) return gc_fail(GC_ERR_HIP, "gc_acq_set_step_two: %s", hipGetErrorString(e));
+    a->wipe2_valid = true;
     a->step_two = true;
     a->center_step_two = doppler_center_hz;
     a->n_bins = n2;
@@ -619,6 +615,8 @@ static gc_status acq_enqueue(gc_acq* a, const void* dev_iq_in, int iq_format, hi
 {
     for (int s = 0; s < a->n_sats; s++)
         if (!a->code_set[s]) return gc_fail(GC_ERR_STATE, "gc_acq_dwell: satellite slot %d has no local code", s);
+    if (!(a->step_two ? a->wipe2_valid : a->wipe_valid))
+        return gc_fail(GC_ERR_STATE, "gc_acq_dwell: the Doppler wipe-off tables are not valid (a rebuild failed): call gc_acq_set_frequency_offset / gc_acq_set_step_two again");
     const float2* dev_iq = static_cast<const float2*>(dev_iq_in);
     if (iq_format != GC_IQ_F32)
         {
@@ -801,6 +799,73 @@ gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid)
     GC_HIP(acq_flush_inverse(a, a->ctx->stream));
     GC_HIP(hipStreamSynchronize(a->ctx->stream));
     GC_HIP(hipMemcpy(host_grid, a->d_grid + (size_t)sat * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    return GC_OK;
+}
+
+// row-permuted P[a][b] = v[a + N1 b]  ->  natural order
+static void acq_unpermute(const AcqFftPlan& plan, const float2* p, float* out)
+{
+    for (int a = 0; a < plan.N1; a++)
+        for (int b = 0; b < plan.N2; b++)
+            {
+                const float2 v = p[(size_t)a * plan.N2 + b];
+                out[2 * ((size_t)a + (size_t)plan.N1 * b)] = v.x;
+                out[2 * ((size_t)a + (size_t)plan.N1 * b) + 1] = v.y;
+            }
+}
+
+gc_status gc_acq_peek(gc_acq* a, int what, int index, float* host_out)
+{
+    GC_REQUIRE(a && host_out, "gc_acq_peek: NULL argument");
+    gc_device_guard g(a->ctx->device);
+    std::lock_guard<std::mutex> lk(a->ctx->mtx);
+    hipStream_t st = a->ctx->stream;
+    const size_t N = a->fft_size;
+    GC_HIP(acq_flush_inverse(a, st));
+    GC_HIP(hipStreamSynchronize(st));
+    if (what == GC_ACQ_PEEK_ROW_MAX)
+        {
+            GC_REQUIRE(index >= 0 && index < a->n_sats, "gc_acq_peek: satellite slot %d out of range", index);
+            const size_t n = (size_t)a->n_bins * a->n_blocks;
+            std::vector<float> v(n);
+            std::vector<unsigned> ix(n);
+            GC_HIP(hipMemcpy(v.data(), a->d_blkv + (size_t)index * n, n * sizeof(float), hipMemcpyDeviceToHost));
+            GC_HIP(hipMemcpy(ix.data(), a->d_blki + (size_t)index * n, n * sizeof(unsigned), hipMemcpyDeviceToHost));
+            for (uint32_t d = 0; d < a->n_bins; d++)
+                {
+                    float best = -1.0f;
+                    unsigned bi = 0xffffffffu;
+                    for (int b = 0; b < a->n_blocks; b++)
+                        {
+                            const size_t e = (size_t)d * a->n_blocks + b;
+                            if (ix[e] == 0xffffffffu) continue;
+                            if (v[e] > best || (v[e] == best && ix[e] < bi))
+                                {
+                                    best = v[e];
+                                    bi = ix[e];
+                                }
+                        }
+                    host_out[2 * d] = best;
+                    host_out[2 * d + 1] = (float)bi;
+                }
+            return GC_OK;
+        }
+    const float2* src = nullptr;
+    if (what == GC_ACQ_PEEK_WIPEOFF || what == GC_ACQ_PEEK_SPECTRUM)
+        {
+            GC_REQUIRE(index >= 0 && (uint32_t)index < a->n_bins, "gc_acq_peek: Doppler bin %d out of range", index);
+            src = (what == GC_ACQ_PEEK_WIPEOFF ? a->d_wipe : a->d_X) + (size_t)index * N;
+        }
+    else if (what == GC_ACQ_PEEK_CODE)
+        {
+            GC_REQUIRE(index >= 0 && index < a->n_sats, "gc_acq_peek: satellite slot %d out of range", index);
+            src = a->d_codes + (size_t)index * N;
+        }
+    else
+        return gc_fail(GC_ERR_INVALID, "gc_acq_peek: unknown item %d", what);
+    std::vector<float2> p(N);
+    GC_HIP(hipMemcpy(p.data(), src, N * sizeof(float2), hipMemcpyDeviceToHost));
+    acq_unpermute(a->plan, p.data(), host_out);  // all three live in the row-permuted layout
     return GC_OK;
 }
 

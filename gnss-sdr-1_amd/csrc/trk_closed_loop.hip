@@ -1445,16 +1445,20 @@ static gc_status loop_launch(gc_trk_loop* l, int n_epochs, gc_loop_record* dev_r
     const bool pilot = l->pilot > 0;
     // LDS code image: the doubled resident one (2 L + 64 floats per replica, loaded once per launch) when it fits beside the
     // header, else the per-period window (L + 64)
+    // header, else the per-period window (L + 64).  With more channels than CUs several workgroups share a CU's 160 KB: the resident
+    // image is then taken only while two workgroups still fit (<= 64 KiB each; Galileo E1 with the pilot's data component is 131 KB:
+    // one workgroup per CU, which only costs nothing while every channel has a CU to itself)
+    const int n_cus = l->ctx->n_cus > 0 ? l->ctx->n_cus : 256;
     int lds_table_floats = (2 * l->max_code_len + 64) * (pilot ? 2 : 1);
     int resident = 1;
-    if ((size_t)(trk_hdr_floats(1024) + lds_table_floats) * sizeof(float) > 150 * 1024)
+    const size_t resident_bytes = (size_t)(trk_hdr_floats(1024) + lds_table_floats) * sizeof(float);
+    if (resident_bytes > 150 * 1024 || (l->n_channels > n_cus && resident_bytes > 64 * 1024))
         {
             lds_table_floats = (l->max_code_len + 64) * (pilot ? 2 : 1);
             resident = 0;
         }
     // few channels: more threads each, so that a channel's epoch is spread over a whole CU (measured, 256 channels x 64
     // epochs on 256 CUs: 0.89 / 0.65 / 0.69 ms with 256 / 512 / 1024 threads)
-    const int n_cus = l->ctx->n_cus > 0 ? l->ctx->n_cus : 256;
     const int threads = l->forced_threads ? l->forced_threads : (2 * l->n_channels <= n_cus ? 1024 : l->n_channels <= 2 * n_cus ? 512 : 256);
     const size_t lds_bytes = (size_t)(trk_hdr_floats(threads) + lds_table_floats) * sizeof(float);
     // workgroups per channel-period: 1 = the persistent one-workgroup-per-channel kernel (always, in the product library); an

@@ -246,6 +246,7 @@ API = {
     "gc_acq_fetch_results": (C.c_int, [_vp, C.POINTER(AcqResult), _vp]),
     "gc_acq_flush": (C.c_int, [_vp, _vp]),
     "gc_acq_get_grid": (C.c_int, [_vp, C.c_int, _fp]),
+    "gc_acq_peek": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
 }
 
 _lib = None
@@ -872,6 +873,18 @@ class PcpsAcquisition:
         g = np.zeros((self.num_doppler_bins, self.fft_size), np.float32)
         _check(load_library().gc_acq_get_grid(self._h, sat, _f32p(g)))
         return g
+
+    PEEK_WIPEOFF, PEEK_SPECTRUM, PEEK_CODE, PEEK_ROW_MAX = 0, 1, 2, 3
+
+    def peek(self, what, index):
+        """gc_acq_peek: a device-resident intermediate in natural order (complex64[fft_size], or float32[num_doppler_bins, 2]
+        = (row maximum, its index) for PEEK_ROW_MAX)."""
+        if what == self.PEEK_ROW_MAX:
+            out = np.zeros((self.num_doppler_bins, 2), np.float32)
+        else:
+            out = np.zeros(2 * self.fft_size, np.float32)
+        _check(load_library().gc_acq_peek(self._h, int(what), int(index), _f32p(out)))
+        return out if what == self.PEEK_ROW_MAX else out.view(np.complex64)
 
     def close(self):
         if self._h:

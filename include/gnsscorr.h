@@ -543,6 +543,16 @@ gc_status gc_acq_flush(gc_acq* a, void* stream);
 gc_status gc_acq_dwell_stream(gc_acq* a, gc_stream* s, uint64_t first_index, gc_acq_result* host_results);
 /* Copies satellite `sat`'s magnitude grid (num_doppler_bins * fft_size floats) to host. */
 gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid);
+/* Inspection of the engine's device-resident intermediates (tests, failure dumps; synchronises the context stream; natural element
+ * order whatever the layout in HBM).  `what`:
+ *   GC_ACQ_PEEK_WIPEOFF   index = Doppler bin: the wipe-off row exp(-j phase) of the ACTIVE grid, d_grid_doppler_wipeoffs[bin]
+ *                         (pcps_acquisition.cc:296-310), fft_size complex values = 2 * fft_size floats
+ *   GC_ACQ_PEEK_SPECTRUM  index = Doppler bin: FFT(x * wipeoff[bin]) of the last dwell's block (:721), 2 * fft_size floats
+ *   GC_ACQ_PEEK_CODE      index = satellite slot: conj(FFT(code)) (d_fft_codes, :272-273), 2 * fft_size floats
+ *   GC_ACQ_PEEK_ROW_MAX   index = satellite slot: per Doppler bin the maximum of the grid row and its position as the statistics
+ *                         kernel sees them (the column pass's block maxima, combined): 2 * num_doppler_bins floats (value, index) */
+enum { GC_ACQ_PEEK_WIPEOFF = 0, GC_ACQ_PEEK_SPECTRUM = 1, GC_ACQ_PEEK_CODE = 2, GC_ACQ_PEEK_ROW_MAX = 3 };
+gc_status gc_acq_peek(gc_acq* a, int what, int index, float* host_out);
 
 #define GC_ABI_CHECK() \
     gc_abi_check(sizeof(gc_epoch_params), sizeof(gc_loop_conf), sizeof(gc_loop_record), sizeof(gc_loop_sync_conf), sizeof(gc_acq_conf), sizeof(gc_acq_result))

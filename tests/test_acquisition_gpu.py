@@ -302,6 +302,90 @@ def test_glonass_l1_real_capture(gctx, oracle):
     acq.close()
 
 
+def _engine_against_oracle_everywhere(acq, p, x, bins):
+    """One search on `acq` and on the oracle block `p`, then every stage of the engine against the oracle's: the wipe-off rows
+    (the oracle's s32f_sincos table is pinned to the compiled reference), FFT(x * wipeoff[bin]) of a few bins, the code spectrum,
+    the WHOLE grid, the row maxima the statistics kernel scans, and the result."""
+    r = acq.dwell(x)[0]
+    q = p.core(x)
+    N = acq.fft_size
+    W = p.wipeoffs()
+    for b in bins:
+        w = acq.peek(acq.PEEK_WIPEOFF, b)
+        # sincosf of the GPU and of the host libm may differ in the last bit; the running phase itself is exact
+        assert np.max(np.abs(w - W[b])) <= 2e-6, "wipe-off row %d" % b
+        X = np.fft.fft(x[:N].astype(np.complex128) * W[b].astype(np.complex128))
+        assert np.max(np.abs(acq.peek(acq.PEEK_SPECTRUM, b) - X)) <= 2e-6 * np.max(np.abs(X)) * np.sqrt(N), "spectrum of bin %d" % b
+    fc = p.fft_codes()
+    assert np.max(np.abs(acq.peek(acq.PEEK_CODE, 0) - fc)) <= 2e-6 * np.max(np.abs(fc)) * np.sqrt(N)
+    grid, ref = acq.grid(0), p.grid()
+    bad = np.argwhere(np.abs(grid - ref) > TOL * ref.max())
+    assert bad.size == 0, "grid differs in %d cells, first (bin, index) %s" % (len(bad), bad[:4].tolist())
+    rm = acq.peek(acq.PEEK_ROW_MAX, 0)
+    assert np.array_equal(rm[:, 1].astype(np.int64), grid.argmax(axis=1)) and np.array_equal(rm[:, 0], grid.max(axis=1))
+    _check(r, q)
+    return r
+
+
+def test_engine_reuse_after_frequency_offset_whole_grid(gctx, oracle):
+    """The sequence of the one red run of round 3 (`adapter_selftest` GLONASS block, pcps_acquisition.cc:239-247, :296-310, :371-380):
+    ONE engine searches frequency channel 0, has its wipe-off tables rebuilt for channel -4 (set_frequency_offset) and its code
+    re-installed (set_local_code), and searches again -- at N = 6625 = 5^3 x 53 (general row kernel, prime radix 53) on the real
+    capture.  Every stage is compared with the oracle after each search, not only the peak cell; the second search's peak is the
+    one the self-test expects (delay 502, 3000 Hz)."""
+    import gnsscorr
+    k, x = _kat("glonass_l1_ca")
+    fs = k["fs"]
+    c = dict(fs_in=fs, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(fs) * np.float32(0.001), samples_per_code=6625.0,
+        samples_per_chip=13, doppler_max=k["doppler_max"], doppler_step=k["doppler_step"])
+    code = gnsscorr.glonass_l1_ca_code_gen_complex_sampled(fs)
+    x = x[:6625]
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, **c)
+    acq.set_local_code(0, code)
+    p = oracle.pcps(**c)
+    p.set_local_code(code)
+    bins = (0, 28, 29, 50, 51, 52, 53, 54, 79)
+    r = _engine_against_oracle_everywhere(acq, p, x, bins)
+    assert (r.indext, r.doppler_hz) == (1344, -2750)
+    for kc, want in ((-4, (502, 3000)), (0, (1344, -2750)), (-4, (502, 3000))):
+        acq.reset()
+        acq.set_frequency_offset(k["dfrq1_glo_hz"] * kc)
+        acq.set_local_code(0, code)
+        p = oracle.pcps(**c)
+        p.set_local_code(code)
+        p.set_frequency_offset(k["dfrq1_glo_hz"] * kc)
+        r = _engine_against_oracle_everywhere(acq, p, x, bins)
+        assert (r.indext, r.doppler_hz) == want
+    acq.close()
+
+
+def test_engine_reuse_after_frequency_offset_whole_grid_25msps(gctx, oracle):
+    """The same reuse sequence at N = 25000 (the pair row kernel and the 25-point column pass of the bench configuration), 40 bins:
+    search, rebuild the tables with an intermediate-frequency offset the signal really has, re-install the code, search."""
+    import gnsscorr
+    from helpers import synth_stream
+    fs, N = 25_000_000, 25000
+    code_chips = oracle.gps_l1_ca_code(7)
+    x, truth = synth_stream([code_chips], fs, N, seed=2504, cn0_db_hz=(47.0, 47.0), doppler_max=4000.0)
+    offset = 1_250_000
+    xo = (x * np.exp(2j * np.pi * offset * np.arange(N) / fs)).astype(np.complex64)
+    c = _conf(fs, 1, 1, float(N), 5000, 250)  # 40 bins (the oracle block has the reference's bin count, no override)
+    code = oracle.gps_l1_ca_code_sampled(7, fs)
+    acq = gnsscorr.PcpsAcquisition(gctx, 1, **c)
+    acq.set_local_code(0, code)
+    bins = (0, 19, 20, 21, 39)
+    for off, sig in ((0, x), (offset, xo), (0, x), (offset, xo)):
+        acq.reset()
+        acq.set_frequency_offset(off)
+        acq.set_local_code(0, code)
+        p = oracle.pcps(**c)
+        p.set_local_code(code)
+        p.set_frequency_offset(off)
+        r = _engine_against_oracle_everywhere(acq, p, sig, bins)
+        assert abs(r.doppler_hz - truth[0]["doppler"]) <= 250
+    acq.close()
+
+
 def test_galileo_e1_real_capture_batched(gctx, oracle):
     """Real Galileo E1 data (GSoC 2012 roof capture, with the MATLAB analysis the reference ships beside it): PRN 11 and 12
     present, 19 and 20 absent, searched in one batched call on a 160-bin grid; every result equals the oracle's cell for

@@ -68,6 +68,38 @@ def test_closed_loop_matches_cpu_restatement(gctx, oracle):
     assert abs(rec["carrier_lock_test"][-1] - ref[-1]["lock_test"]) < 1e-3 and rec["carrier_lock_test"][-1] > 0.8
 
 
+def test_closed_loop_period_longer_than_the_code_table(gctx, oracle):
+    """A code period declared as 2046 chips (2 ms, 8000 samples) on a 1023-entry replica table: the chips a period touches
+    (2046 + the tap spread) exceed L + 64, so the kernel cannot address a window inside its resident doubled image and takes the
+    `index mod L` form on the image's first L entries (trk_device.hpp, `resident && !windowed`) -- a branch no other closed-loop
+    case reaches.  Same checks as the plain case, against the CPU restatement."""
+    import gnsscorr
+    import torch
+    from closed_loop_ref import run as ref_run
+    fs, n_ep = 4e6, 60
+    code, x = _signal(oracle, 9, fs, 8000 * (n_ep + 3), 414, -2210.0, 777.0)
+    conf = dict(GPS, code_length_chips=2046, code_period_s=0.002, vector_length=8000, acq_delay_samples=777.0, acq_doppler_hz=-2200.0,
+        acq_samplestamp_samples=0, sample_counter=0)
+    ref = ref_run(oracle, x, code, conf, n_ep)
+    d = torch.from_numpy(x.view(np.float32)).cuda()
+    loop = gnsscorr.TrackingLoop(gctx, 1, 1023)
+    loop.set_input_dev(0, d.data_ptr(), x.size)
+    loop.start(0, _conf(gnsscorr, **conf), code)
+    rec = loop.run(n_ep)[0]
+    loop.close()
+    assert np.all(rec["valid"] == 1) and len(ref) == n_ep
+    for k in range(n_ep):
+        r, g = ref[k], rec[k]
+        assert int(g["sample_counter"]) == r["sample_counter"], k
+        assert int(g["current_prn_length_samples"]) == r["cur"] and 7990 < r["cur"] < 8010
+        gp = g["corr"][2] + 1j * g["corr"][3]
+        assert abs(gp - r["corr"][1]) <= 2e-3 * abs(r["corr"][1])
+        assert abs(float(g["carrier_doppler_hz"]) - r["doppler"]) < 0.05
+    assert abs(rec["carrier_doppler_hz"][-20:].mean() + 2210.0) < 3.0
+    p = rec["corr"][-20:, 2] + 1j * rec["corr"][-20:, 3]
+    assert np.mean(np.abs(p)) > 0.6 * np.sqrt(10 ** 4.6 / fs) * 8000  # both code periods of the block add up
+
+
 def test_closed_loop_many_channels_and_restart(gctx, oracle):
     """32 channels in one launch on a shared stream; the state persists across launches (2 x 40 epochs ==
     1 x 80 epochs); an exhausted input yields invalid records."""

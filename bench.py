@@ -17,7 +17,16 @@ stream, served from L2 / Infinity Cache) is reported beside it, not as `value`.
 Multi-GPU (driver: python -m torch.distributed.run --nproc-per-node N bench.py
 --gpus N ...): channels shard over ranks (32 per GPU, BASELINE configs[4]), no
 data-path collective; RCCL is used only for the barrier and the max-over-ranks
-of the elapsed time.  scaling = "weak".
+of the elapsed time.  scaling = "weak".  Behind the headline region every rank
+also times ITS share of BASELINE configs[4] (16 GPS L1 C/A + 8 Galileo E1 5-tap
++ 8 BeiDou B1I channels, open loop) and its PRNs of the configs[3] search
+(PRN i on GPU (i - 1) mod G); both travel in `per_gpu[]`, their sums in
+`hybrid_all_gpus` / `acquisition_all_gpus`.
+
+The headline is the contract's region: W warm-up steps, then K timed steps
+(no pre-roll by default).  On this chip that region lies inside a start-of-load
+power transient; the figure after ~10 ms of load is reported beside it as
+`roofline.steady_state_frac` (and `--preroll-ms 15` moves the timed region there).
 """
 import argparse
 import json
@@ -68,11 +77,13 @@ def gps_ca_code(prn):
     return out
 
 
-def make_channel_stream(torch, dev, code, n_samples, seed):
+def make_channel_stream(torch, dev, code, n_samples, seed, cn0_db_hz=None):
     """Seeded synthetic IQ for one channel: unit-variance complex noise + one
     PRN at C/N0 in [38, 48] dB-Hz, Doppler in +-5 kHz."""
     rng = np.random.Generator(np.random.PCG64(seed))
     cn0 = rng.uniform(38.0, 48.0)
+    if cn0_db_hz is not None:
+        cn0 = cn0_db_hz
     amp = float(np.sqrt(10.0 ** (cn0 / 10.0) / FS))
     fd = float(rng.uniform(-5000.0, 5000.0))
     tau0 = float(rng.uniform(0, CODE_LEN))
@@ -201,13 +212,15 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-acq", action="store_true")
     ap.add_argument("--acq-reps", type=int, default=5, help="timed acquisition searches (profiles/collect.sh counts on this)")
-    ap.add_argument("--acq-warmup", type=int, default=20, help="untimed acquisition searches in front of the timed ones (named in the JSON)")
+    ap.add_argument("--acq-warmup", type=int, default=1, help="untimed acquisition searches in front of the timed ones (named in the JSON; "
+        "the steady-state figure behind 20 of them is reported beside it as `steady_state`)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-shared", action="store_true", help="skip the shared-stream extra (clean rocprof runs)")
     ap.add_argument("--segments", type=int, default=24, help="untimed diagnostic pass behind the timed region: this many segments of "
         "5 back-to-back launches, one HIP event between segments (0: skip)")
-    ap.add_argument("--preroll-ms", type=float, default=15.0, help="untimed launches of the same step IN FRONT of the W warm-up steps, "
-        "about this many ms of GPU time (named in the JSON line as `preroll`; 0: none, the timed region then starts W steps after idle)")
+    ap.add_argument("--preroll-ms", type=float, default=0.0, help="untimed launches of the same step IN FRONT of the W warm-up steps, "
+        "about this many ms of GPU time (named in the JSON line as `preroll`).  Default 0: the headline is the contract's region, W "
+        "warm-up steps then K timed ones; the steady-state figure is reported beside it as roofline.steady_state_frac")
     args = ap.parse_args()
 
     import torch
@@ -351,6 +364,164 @@ def main():
         "steady_state_kernel_ms": steady_ms,
         "steady_state_hbm_frac": (alg_bytes / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if steady_ms else None,
         "cold_start_kernel_ms": cold_ms}
+
+    vceil = load_valu_ceilings()
+
+    # ---- BASELINE configs[4], one GPU's share: 32 channels = 16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I, open loop.
+    # EVERY rank times its own share (gnss_flowgraph.cc:496-499: every channel hangs on the one conditioner output; here channel g of
+    # the 256 runs on GPU g mod G with 32 per GPU, and each GPU holds the same mix) ----
+    def run_hybrid():
+        rng_h = np.random.Generator(np.random.PCG64(1005 + rank))
+        hb = []  # (batch, n_epochs, params, out, samples)
+        def add_group(first_ch, n_ch, n_taps, L, n_len, step_chips, hshifts):
+            b = gnsscorr.TrackingBatch(ctx, n_ch, n_taps, L)
+            n_ep = max(1, (E * N_EPOCH) // n_len)
+            recs = []
+            for k in range(n_ch):
+                b.set_code(k, np.sign(rng_h.standard_normal(L)).astype(np.float32), hshifts)
+                b.set_input_dev(k, streams[first_ch + k].data_ptr(), n_stream)
+                recs.append([gnsscorr.epoch_params(e * n_len, 0.1, 1e-3, 0.3, float(np.float32(step_chips)), n_len) for e in range(n_ep)])
+            d_p = torch.from_numpy(gnsscorr.epoch_params_array(recs).view(np.uint8)).to(dev)
+            d_o = torch.zeros(n_ch * n_ep * n_taps, 2, device=dev, dtype=torch.float32)
+            hb.append((b, n_ep, d_p, d_o, n_ch * n_ep * n_len))
+        add_group(0, 16, 3, 1023, N_EPOCH, 1.023e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
+        add_group(16, 8, 5, 8184, 4 * N_EPOCH, 2.046e6 / FS, np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32))
+        add_group(24, 8, 3, 2046, N_EPOCH, 2.046e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
+        def hybrid_step():
+            for b, n_ep, d_p, d_o, _ in hb:
+                b.run_dev(n_ep, d_p.data_ptr(), d_o.data_ptr(), stream)
+        for _ in range(2):
+            hybrid_step()
+        torch.cuda.synchronize()
+        h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0.record()
+        for _ in range(args.steps):
+            hybrid_step()
+        h1.record()
+        torch.cuda.synchronize()
+        hyb_ms = h0.elapsed_time(h1) / args.steps
+        hyb_samples = sum(g[4] for g in hb)
+        res = {"value": hyb_samples / (hyb_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": hyb_ms,
+            "hbm_gbps": 8.0 * hyb_samples / (hyb_ms * 1e-3) / 1e9, "realtime_factor_32ch": hyb_samples / (hyb_ms * 1e-3) / (32 * FS),
+            "note": "one GPU's share of the 256-channel hybrid: 16 GPS L1 C/A (3 taps) + 8 Galileo E1 (5 taps, L = 8184, 4 ms) + 8 BeiDou B1I "
+                    "(3 taps, L = 2046), 25 Msps, distinct IQ buffer per channel, three launches per step",
+            "roofline": mode_roofline(vceil, [(hb[0][4], 8.0, "gps_l1_3tap_f32", 1.0), (hb[1][4], 8.0, "galileo_5tap_f32", 1.0),
+                (hb[2][4], 8.0, "gps_l1_3tap_f32", 1.0)], hyb_ms)}
+        for g in hb:
+            g[0].close()
+        return res
+
+    # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps; with G GPUs the (PRN, dwell) jobs shard like the
+    # channels: this rank searches PRNs rank + 1, rank + 1 + G, ... on its first RF stream ----
+    def run_acquisition(prn_ids, warmups):
+        n_sat, n_bins_acq, n_dw = len(prn_ids), 41, 2
+        acq = gnsscorr.PcpsAcquisition(ctx, n_sat, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,
+            5000, 250, max_dwells=n_dw, use_cfar=False, num_doppler_bins_override=n_bins_acq)
+        sampled = []
+        for s_, pid in enumerate(prn_ids):
+            code = gps_ca_code(pid % 32 + 1)
+            idx = np.minimum((np.arange(N_EPOCH) * (1.023e6 / FS)).astype(np.int64), 1022)
+            sampled.append(code[idx].astype(np.complex64))
+            acq.set_local_code(s_, sampled[-1])
+        # the searched block: two code periods of an RF stream of this rank's own, carrying ONE satellite -- the first PRN of the rank's
+        # set, at 47 dB-Hz so that 2 x 1 ms finds it among n_sat x 41 x 25000 cells whatever the rank (the tracking streams hold their
+        # satellites at 38-48 dB-Hz; the search time does not depend on the samples)
+        ch_x = 0
+        x, t_acq = make_channel_stream(torch, dev, gps_ca_code(prn_ids[0] % 32 + 1), 2 * N_EPOCH + 64, seed=5003 + 11 * rank, cn0_db_hz=47.0)
+        torch.cuda.synchronize()
+        def acq_search():
+            acq.reset()
+            acq.dwell_enqueue(x.data_ptr(), stream)
+            acq.dwell_enqueue(x.data_ptr() + 8 * N_EPOCH, stream)
+            acq.flush(stream)  # this search's own statistics kernel, enqueued behind its passes (no host synchronisation)
+        def timed(n_warm, reps):
+            for _ in range(n_warm):
+                acq_search()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()  # one pair of events around all the searches (a pair per search idles the GPU ~12 us between searches)
+            for _ in range(reps):
+                acq_search()
+            a1.record()
+            torch.cuda.synchronize()
+            return float(a0.elapsed_time(a1)) / reps
+        reps = args.acq_reps
+        acq_ms = timed(max(1, warmups), reps)
+        # the same searches again behind ~6 ms of the same load (20 searches): the steady-clock figure, reported beside the headline one
+        steady_ms = timed(20, reps) if args.segments > 0 else None
+        # sanity: the searched stream carries ONE satellite -- its slot must win, at its code phase and in its Doppler bin
+        ares = acq.fetch_results(stream)
+        stats = np.array([r.test_statistics for r in ares])
+        t_a = t_acq
+        want_delay = ((CODE_LEN - t_a["tau0"]) % CODE_LEN) * FS / 1.023e6
+        d_err = abs(ares[ch_x].indext - want_delay)
+        assert int(np.argmax(stats)) == ch_x and min(d_err, N_EPOCH - d_err) <= 26 and abs(ares[ch_x].doppler_hz - t_a["doppler"]) <= 250, \
+            ("acquisition lost its PRN", ch_x, stats[:4], ares[ch_x].indext, want_delay, ares[ch_x].doppler_hz, t_a["doppler"])
+        # Algorithmic bytes per (PRN, bin, dwell) cell: read X 8N + read conj-FFT(code) 8N + write |.|^2 4N,
+        # + 4N read when a later dwell accumulates: 20N for dwell 1, 24N for dwell 2
+        cells = n_sat * n_bins_acq
+        acq_alg = float(cells * N_EPOCH * (20 + 24))
+        acq_gbps = acq_alg / (acq_ms * 1e-3) / 1e9
+        aroof = {"bound": "hbm", "achieved": acq_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": acq_gbps / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_search": acq_alg, "search_ms": acq_ms,
+            "steady_state_search_ms": steady_ms, "steady_state_frac": (acq_alg / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if steady_ms else None,
+            "note": "whole search (2 dwells: shared forward transforms, inverse row + column passes of every cell, its own statistics "
+                    "kernel via gc_acq_flush) timed with HIP events on the launch stream; achieved = algorithmic bytes / that time; "
+                    "steady_state_* = the same behind 20 untimed searches", "traffic": None}
+        apath = os.path.join(ROOT, "profiles", "acq_latest.json")
+        if os.path.exists(apath) and n_sat == 32:
+            try:
+                aj = json.load(open(apath))
+                aroof["traffic"] = aj.get("hbm_bytes_per_search")
+                aroof["traffic_source"] = "profiles/acq_latest.json (round %s rocprofv3 PMC passes of this workload; not measured in this run)" % aj.get("round")
+                aroof["dominant_kernel"] = aj.get("dominant_kernel")
+                aroof["dominant_kernel_us_per_launch"] = aj.get("dominant_kernel_us")
+            except Exception:
+                pass
+        res = {"dwells_per_s": n_sat * n_dw / (acq_ms * 1e-3), "ms_per_search": acq_ms,
+            "timed_searches": reps, "warmup_searches": max(1, warmups), "prns": [pid % 32 + 1 for pid in prn_ids],
+            "workload": "GPS L1 C/A PCPS, 25 Msps, N=25000, %d PRNs x 41 Doppler bins x 2 dwells" % n_sat, "roofline": aroof}
+        if not args.no_cpu and world == 1:
+            # CPU baseline of the same search: the oracle's acquisition_core restatement (own float64 mixed-radix FFT, gcc -O3
+            # -march=native, 1 thread) on a bounded sample: PRN-dwells of the same block sizes and Doppler grid
+            from oracle import Oracle, host_cpu_model
+            orc = Oracle(native=True)
+            xh = x[:2 * N_EPOCH].cpu().numpy().view(np.complex64).reshape(-1)
+            pc = orc.pcps(fs_in=FS, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(FS) * np.float32(0.001), samples_per_code=25000.0,
+                samples_per_chip=25, doppler_max=5125, doppler_step=250, max_dwells=n_dw)  # ceil(10250 / 250) = 41 bins
+            pc.set_local_code(sampled[ch_x])
+            n_done, t0c = 0, time.perf_counter()
+            while time.perf_counter() - t0c < args.cpu_seconds * 0.5:
+                pc.reset_grid()
+                for d_ in range(n_dw):
+                    pc.core(xh[d_ * N_EPOCH:])
+                    n_done += 1
+            dtc = time.perf_counter() - t0c
+            res["cpu_baseline"] = {"value": n_done / dtc, "unit": "dwells/s", "cores": 1, "kind": "port",
+                "sample": "%d PRN-dwells (41 Doppler bins x N=25000 each, 2-dwell searches of PRN 1) in %.1f s, oracle PCPS: float64 "
+                          "mixed-radix FFT port, NOT the reference's FFTW3f float32 path (pcps_acquisition.cc:721-727), so far slower than "
+                          "the real block; gcc -O3 -march=native built on this host (%s), 1 thread" % (n_done, dtc, host_cpu_model())}
+        acq.close()
+        return res
+
+    # every rank's share of BASELINE configs[4] (the hybrid mix) and of configs[3] (its PRNs of the 32), timed behind the headline
+    # region with no barrier in between: nothing waits on another rank's extras; the figures travel in per_gpu[]
+    share = None
+    if world > 1 or not (args.no_shared and args.no_acq):
+        share = {"hybrid": None, "acquisition": None}
+        if world > 1 or not args.no_shared:
+            share["hybrid"] = run_hybrid()
+        if not args.no_acq:
+            share["acquisition"] = run_acquisition(sharding.shard_channels(32, world, rank), args.acq_warmup)
+        if share["hybrid"] is not None:
+            mine["hybrid_msamples_s"] = share["hybrid"]["value"]
+            mine["hybrid_frac"] = share["hybrid"]["roofline"]["frac"]
+            mine["hybrid_hbm_frac"] = share["hybrid"]["roofline"]["hbm_frac"]
+        if share["acquisition"] is not None:
+            mine["acq_dwells_per_s"] = share["acquisition"]["dwells_per_s"]
+            mine["acq_ms_per_search"] = share["acquisition"]["ms_per_search"]
+            mine["acq_hbm_frac"] = share["acquisition"]["roofline"]["frac"]
+            mine["acq_prns"] = share["acquisition"]["prns"]
     per_gpu = sharding.gather_per_rank(mine, dist, world)
 
     # sanity: the prompt correlators see their signals (guards against timing a broken path)
@@ -362,11 +533,10 @@ def main():
     result = None
     if rank == 0:
         extra = {}
-        vceil = load_valu_ceilings()
-        # the extras below are single-GPU side measurements: in a multi-GPU run the other ranks would only wait for them
+        # the extras below (other than every rank's hybrid / acquisition share) are single-GPU side measurements: in a multi-GPU run
+        # the other ranks would only wait for them
         if world > 1:
             args.no_shared = True
-            args.no_acq = True
         # ---- shared-stream mode: all 32 channels on ONE RF stream (cache-served) ----
         if not args.no_shared:
             for ch in range(N_CHANNELS):
@@ -449,46 +619,14 @@ def main():
                 "roofline": mode_roofline(vceil, [(gal_samples, 8.0, "galileo_5tap_f32", 1.0)], gal_ms)}
             bg.close()
 
-        # ---- BASELINE configs[4] per-GPU share: 32 channels = 16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I ----
-        if not args.no_shared:
-            rng_h = np.random.Generator(np.random.PCG64(1005))
-            hb = []  # (batch, n_epochs, params, out, samples)
-            def add_group(first_ch, n_ch, n_taps, L, n_len, step_chips, hshifts):
-                b = gnsscorr.TrackingBatch(ctx, n_ch, n_taps, L)
-                n_ep = max(1, (E * N_EPOCH) // n_len)
-                recs = []
-                for k in range(n_ch):
-                    b.set_code(k, np.sign(rng_h.standard_normal(L)).astype(np.float32), hshifts)
-                    b.set_input_dev(k, streams[first_ch + k].data_ptr(), n_stream)
-                    recs.append([gnsscorr.epoch_params(e * n_len, 0.1, 1e-3, 0.3, float(np.float32(step_chips)), n_len) for e in range(n_ep)])
-                d_p = torch.from_numpy(gnsscorr.epoch_params_array(recs).view(np.uint8)).to(dev)
-                d_o = torch.zeros(n_ch * n_ep * n_taps, 2, device=dev, dtype=torch.float32)
-                hb.append((b, n_ep, d_p, d_o, n_ch * n_ep * n_len))
-            add_group(0, 16, 3, 1023, N_EPOCH, 1.023e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
-            add_group(16, 8, 5, 8184, 4 * N_EPOCH, 2.046e6 / FS, np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32))
-            add_group(24, 8, 3, 2046, N_EPOCH, 2.046e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
-            def hybrid_step():
-                for b, n_ep, d_p, d_o, _ in hb:
-                    b.run_dev(n_ep, d_p.data_ptr(), d_o.data_ptr(), stream)
-            for _ in range(2):
-                hybrid_step()
-            torch.cuda.synchronize()
-            h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            h0.record()
-            for _ in range(args.steps):
-                hybrid_step()
-            h1.record()
-            torch.cuda.synchronize()
-            hyb_ms = h0.elapsed_time(h1) / args.steps
-            hyb_samples = sum(g[4] for g in hb)
-            extra["hybrid_gps_galileo_beidou"] = {"value": hyb_samples / (hyb_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": hyb_ms,
-                "hbm_gbps": 8.0 * hyb_samples / (hyb_ms * 1e-3) / 1e9, "realtime_factor_32ch": hyb_samples / (hyb_ms * 1e-3) / (32 * FS),
-                "note": "one GPU's share of the 256-channel hybrid: 16 GPS L1 C/A (3 taps) + 8 Galileo E1 (5 taps, L = 8184, 4 ms) + 8 BeiDou B1I "
-                        "(3 taps, L = 2046), 25 Msps, distinct IQ buffer per channel, three launches per step",
-                "roofline": mode_roofline(vceil, [(hb[0][4], 8.0, "gps_l1_3tap_f32", 1.0), (hb[1][4], 8.0, "galileo_5tap_f32", 1.0),
-                    (hb[2][4], 8.0, "gps_l1_3tap_f32", 1.0)], hyb_ms)}
-            for g in hb:
-                g[0].close()
+        if share is not None and share["hybrid"] is not None:
+            extra["hybrid_gps_galileo_beidou"] = share["hybrid"]
+            if world > 1:
+                # BASELINE configs[4]: the 256-channel hybrid over all GPUs = every rank's share side by side (no collective)
+                hv = [g["hybrid_msamples_s"] for g in per_gpu]
+                extra["hybrid_all_gpus"] = {"value": float(sum(hv)), "unit": "Msamples/s", "channels": 32 * world,
+                    "realtime_factor": float(sum(hv)) * 1e6 / (32 * world * FS), "slowest_gpu_msamples_s": float(min(hv)),
+                    "note": "sum of the per-GPU hybrid shares (per_gpu[].hybrid_msamples_s), each timed on its own GPU behind the headline region"}
 
         # ---- host-fed pipeline: one RF stream pushed over PCIe into the HBM ring while the channels track it ----
         if not args.no_shared:
@@ -667,87 +805,15 @@ def main():
                         "period costs ~11 us whatever the channel count (7.5 correlation by one CU + 2.6 one-lane loop maths): cutting periods "
                         "into slices over more CUs was built and measured slower (13.4 us: experiments build, DESIGN.md appendix A)"}
 
-        # ---- acquisition: BASELINE configs[3], 32 PRNs x 41 bins x 2 dwells @ 25 Msps ----
-        if not args.no_acq:
-            n_sat, n_bins_acq, n_dw = 32, 41, 2
-            acq = gnsscorr.PcpsAcquisition(ctx, n_sat, FS, 1, 1, np.float32(FS) * np.float32(0.001), 25000.0, 25,
-                5000, 250, max_dwells=n_dw, use_cfar=False, num_doppler_bins_override=n_bins_acq)
-            sampled = []
-            for s in range(n_sat):
-                code = gps_ca_code(s + 1)
-                idx = np.minimum((np.arange(N_EPOCH) * (1.023e6 / FS)).astype(np.int64), 1022)
-                sampled.append(code[idx].astype(np.complex64))
-                acq.set_local_code(s, sampled[-1])
-            x = streams[0]
-            def acq_search():
-                acq.reset()
-                acq.dwell_enqueue(x.data_ptr(), stream)
-                acq.dwell_enqueue(x.data_ptr() + 8 * N_EPOCH, stream)
-                acq.flush(stream)  # this search's own statistics kernel, enqueued behind its passes (no host synchronisation)
-            # untimed warm-up searches (named in the JSON: `warmup_searches`): ~6 ms of the same load, so that the timed searches
-            # lie behind the start-of-load power transient like the tracking steps do
-            for _ in range(max(1, args.acq_warmup)):
-                acq_search()
-            torch.cuda.synchronize()
-            reps = args.acq_reps
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()  # one pair of events around all the searches (a pair per search idles the GPU ~12 us between searches)
-            for _ in range(reps):
-                acq_search()
-            a1.record()
-            torch.cuda.synchronize()
-            acq_ms = float(a0.elapsed_time(a1)) / reps
-            # sanity: stream 0 carries PRN 1 only -- it must win, at its code phase and in its Doppler bin
-            ares = acq.fetch_results(stream)
-            stats = np.array([r.test_statistics for r in ares])
-            t_a = truths[0]
-            want_delay = ((CODE_LEN - t_a["tau0"]) % CODE_LEN) * FS / 1.023e6
-            d_err = abs(ares[0].indext - want_delay)
-            assert int(np.argmax(stats)) == 0 and min(d_err, N_EPOCH - d_err) <= 26 and abs(ares[0].doppler_hz - t_a["doppler"]) <= 250, \
-                ("acquisition lost PRN 1", stats[:4], ares[0].indext, want_delay, ares[0].doppler_hz, t_a["doppler"])
-            # Algorithmic bytes per (PRN, bin, dwell) cell: read X 8N + read conj-FFT(code) 8N + write |.|^2 4N,
-            # + 4N read when a later dwell accumulates: 20N for dwell 1, 24N for dwell 2
-            cells = n_sat * n_bins_acq
-            acq_alg = float(cells * N_EPOCH * (20 + 24))
-            acq_gbps = acq_alg / (acq_ms * 1e-3) / 1e9
-            aroof = {"bound": "hbm", "achieved": acq_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": acq_gbps / HBM_PEAK_GBPS,
-                "algorithmic_bytes_per_search": acq_alg, "search_ms": acq_ms,
-                "note": "whole search (2 dwells: shared forward transforms, inverse row + column passes of every cell, its own statistics "
-                        "kernel via gc_acq_flush) timed with HIP events on the launch stream; achieved = algorithmic bytes / that time", "traffic": None}
-            apath = os.path.join(ROOT, "profiles", "acq_latest.json")
-            if os.path.exists(apath):
-                try:
-                    aj = json.load(open(apath))
-                    aroof["traffic"] = aj.get("hbm_bytes_per_search")
-                    aroof["traffic_source"] = "profiles/acq_latest.json (round %s rocprofv3 PMC passes of this workload; not measured in this run)" % aj.get("round")
-                    aroof["dominant_kernel"] = aj.get("dominant_kernel")
-                    aroof["dominant_kernel_us_per_launch"] = aj.get("dominant_kernel_us")
-                except Exception:
-                    pass
-            extra["acquisition"] = {"dwells_per_s": n_sat * n_dw / (acq_ms * 1e-3), "ms_per_search": acq_ms,
-                "timed_searches": reps, "warmup_searches": max(1, args.acq_warmup),
-                "workload": "GPS L1 C/A PCPS, 25 Msps, N=25000, 32 PRNs x 41 Doppler bins x 2 dwells", "roofline": aroof}
-            if not args.no_cpu and world == 1:
-                # CPU baseline of the same search: the oracle's acquisition_core restatement (own float64 mixed-radix FFT, gcc -O3
-                # -march=native, 1 thread) on a bounded sample: PRN-dwells of the same block sizes and Doppler grid
-                from oracle import Oracle, host_cpu_model
-                orc = Oracle(native=True)
-                xh = x[:2 * N_EPOCH].cpu().numpy().view(np.complex64).reshape(-1)
-                pc = orc.pcps(fs_in=FS, sampled_ms=1, ms_per_code=1, samples_per_ms=np.float32(FS) * np.float32(0.001), samples_per_code=25000.0,
-                    samples_per_chip=25, doppler_max=5125, doppler_step=250, max_dwells=n_dw)  # ceil(10250 / 250) = 41 bins
-                pc.set_local_code(sampled[0])
-                n_done, t0c = 0, time.perf_counter()
-                while time.perf_counter() - t0c < args.cpu_seconds * 0.5:
-                    pc.reset_grid()
-                    for d_ in range(n_dw):
-                        pc.core(xh[d_ * N_EPOCH:])
-                        n_done += 1
-                dtc = time.perf_counter() - t0c
-                extra["acquisition"]["cpu_baseline"] = {"value": n_done / dtc, "unit": "dwells/s", "cores": 1, "kind": "port",
-                    "sample": "%d PRN-dwells (41 Doppler bins x N=25000 each, 2-dwell searches of PRN 1) in %.1f s, oracle PCPS: float64 "
-                              "mixed-radix FFT port, NOT the reference's FFTW3f float32 path (pcps_acquisition.cc:721-727), so far slower than "
-                              "the real block; gcc -O3 -march=native built on this host (%s), 1 thread" % (n_done, dtc, host_cpu_model())}
-            acq.close()
+        if share is not None and share.get("acquisition") is not None:
+            extra["acquisition"] = share["acquisition"]
+            if world > 1:
+                # BASELINE configs[3] over all GPUs: the 32 PRNs partitioned PRN i -> GPU (i - 1) mod G
+                all_prns = sorted(p_ for g in per_gpu for p_ in g["acq_prns"])
+                extra["acquisition_all_gpus"] = {"dwells_per_s": float(sum(g["acq_dwells_per_s"] for g in per_gpu)),
+                    "search_ms_slowest_gpu": float(max(g["acq_ms_per_search"] for g in per_gpu)), "prns_partition_1_to_32": all_prns == list(range(1, 33)),
+                    "note": "every GPU searches its PRNs (per_gpu[].acq_prns) x 41 bins x 2 dwells on its own RF stream copy; the whole 32-PRN "
+                            "search takes the slowest GPU's time"}
 
         cpu = None
         if not args.no_cpu and world == 1:
@@ -818,7 +884,8 @@ def main():
                         "--preroll-ms 0 removes it; roofline.cold_start_frac is the figure without it"},
             "cpu_baseline": cpu,
             "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
-            "per_gpu": [{k: g[k] for k in ("rank", "msamples_s", "hbm_frac", "kernel_ms", "steady_state_kernel_ms", "steady_state_hbm_frac", "cold_start_kernel_ms")} for g in per_gpu],
+            "per_gpu": [{k: g.get(k) for k in ("rank", "msamples_s", "hbm_frac", "kernel_ms", "steady_state_kernel_ms", "steady_state_hbm_frac", "cold_start_kernel_ms",
+                "hybrid_msamples_s", "hybrid_frac", "hybrid_hbm_frac", "acq_dwells_per_s", "acq_ms_per_search", "acq_hbm_frac", "acq_prns")} for g in per_gpu],
             "slowest_rank": max(per_gpu, key=lambda g: g["elapsed_s"])["rank"],
         }
         result.update(extra)

@@ -32,7 +32,8 @@ def test_bench_under_torchrun_with_rccl_process_group():
 
 def test_two_ranks_report_per_gpu_figures():
     """Two ranks (gloo, both on the one GPU of the box: BENCH_FORCE_DEVICE) through bench.py's N > 1 path: the line carries one
-    per_gpu entry per rank -- own Msamples/s, own kernel time and HBM fraction -- and names the slowest rank."""
+    per_gpu entry per rank -- own Msamples/s, own kernel time and HBM fraction, own hybrid share (BASELINE configs[4]) and own PRNs of
+    the acquisition search (configs[3]) -- and names the slowest rank."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -49,3 +50,11 @@ def test_two_ranks_report_per_gpu_figures():
     # whole-job value = all ranks' units / the slowest rank's time: never above the sum of the per-GPU rates
     assert j["value"] <= sum(g["msamples_s"] for g in j["per_gpu"]) * (1 + 1e-9)
     assert len(j["roofline"]["segments_ms"]) == 4
+    # every rank timed ITS share of BASELINE configs[4] (16 GPS + 8 Galileo 5-tap + 8 BeiDou, open loop) and its PRNs of the cfg4 search
+    # (channel / PRN i on GPU i mod G; gnss_flowgraph.cc:496-499)
+    for g in j["per_gpu"]:
+        assert g["hybrid_msamples_s"] > 0 and 0 < g["hybrid_frac"] < 1.2 and g["acq_dwells_per_s"] > 0 and 0 < g["acq_hbm_frac"] < 1
+    assert j["per_gpu"][0]["acq_prns"] == list(range(1, 33, 2)) and j["per_gpu"][1]["acq_prns"] == list(range(2, 33, 2))
+    assert j["acquisition_all_gpus"]["prns_partition_1_to_32"] is True
+    assert j["acquisition_all_gpus"]["dwells_per_s"] == pytest.approx(sum(g["acq_dwells_per_s"] for g in j["per_gpu"]))
+    assert j["hybrid_all_gpus"]["channels"] == 64 and j["hybrid_all_gpus"]["value"] == pytest.approx(sum(g["hybrid_msamples_s"] for g in j["per_gpu"]))

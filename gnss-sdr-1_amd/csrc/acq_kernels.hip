@@ -857,6 +857,9 @@ static __device__ __forceinline__ void lds_read_pairs10(const float* xr, const f
 #ifndef ACQ_ROWS3_WAVES
 #define ACQ_ROWS3_WAVES 4
 #endif
+#ifndef ACQ_ROWS3_STAGE2_QFAST
+#define ACQ_ROWS3_STAGE2_QFAST 1  // lane -> pair mapping of the second stage (see there)
+#endif
 // slot `slot` of `slots_per_xcd` on XCD `xcd` (the launch decides which blocks those are)
 template <bool INV>
 static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, const AcqRows2Args& g, float2* sm, int xcd, int slot, int slots_per_xcd)
@@ -909,6 +912,25 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
         cell = sat * g.n_bins + bin;
     }
     PkC a[R], tw[R];
+#ifndef ACQ_ROWS3_HOIST_TW
+#define ACQ_ROWS3_HOIST_TW 0  // 1: the twiddle seeds of stages 2 and 3 are requested here, in front of the stage-1 inputs (loads return in order:
+                              // whatever waits for the inputs has them too), instead of at the head of their stages.  Measured (round 4, same box,
+                              // rocprofv3 means of 88 launches): 37.6 / 37.5 us against 36.9 / 38.1 us -- nothing: the 13 % that phase elimination
+                              // attributes to "twiddle loads off" is the arithmetic on constant seeds, not the loads' latency.  Kept as a knob
+#endif
+    const int p2 = p - row * NP;  // pair of the row, 0 .. 49
+    const int u2 = ACQ_ROWS3_STAGE2_QFAST ? 10 * (p2 % 10) + 2 * (p2 / 10) : u;  // this lane's pair in stage 2 (see there)
+    float2 sd2 = make_float2(1.f, 0.f), d3 = make_float2(1.f, 0.f);
+    acq_f32x4 b3 = acq_f32x4{1.f, 0.f, 1.f, 0.f};
+    if (ACQ_ROWS3_HOIST_TW && act && !(ACQ_ROWS3_DBG && (g.dbg & 4)))
+        {
+            sd2 = g.wN2[plan.tw_off[1] + u2 / 10];                                              // w_100^q
+            if (!(ACQ_ROWS3_DBG && (g.dbg & 16)))
+                {
+                    b3 = *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);       // w_N^(k1 r), w_N^(k1 (r + 1))
+                    d3 = g.wN[(size_t)k1 * N2 + 100];                                           // w_N^(100 k1)
+                }
+        }
     // ---- stage 1: S = 1, M = 100; butterflies q = u, u + 1; inputs x[q + 100 j] from global memory (x the code spectrum) ----
     if (act)
         {
@@ -919,7 +941,7 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
 #pragma unroll
                     for (int j = 0; j < R; j++) a[j] = PkC{acq_pk2{(float)(u + j), 1.0f}, acq_pk2{0.5f, (float)j}};
                 }
-            else if (g.B)
+            else if (g.B && !(ACQ_ROWS3_DBG && (g.dbg & 16)))
                 {
                     const float2* bp = g.B + (size_t)sat * N + (size_t)k1 * N2 + u;
 #pragma unroll
@@ -959,15 +981,21 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
             *reinterpret_cast<acq_f32x4*>(yi + 16) = acq_f32x4{a[6].i.y, a[7].i.y, a[8].i.y, a[9].i.y};
         }
     __syncthreads();
-    // ---- stage 2: S = 10, M = 10; u = 10 q + r, the pair shares q; inputs x[r + 10 q + 100 j] ----
+    // ---- stage 2: S = 10, M = 10; butterflies u2 = 10 q + r, the pair shares q; inputs x[r + 10 q + 100 j] ----
+    // Which pair of the row a lane takes in THIS stage is free (stage 1 wrote and stage 3 reads by position, not by owner).  With
+    // consecutive lanes on consecutive r (q = lane / 5) the 8-byte stores of a 16-lane group fall into three 10-dword runs 100 dwords
+    // apart, i.e. 4, 8 and 12 banks apart modulo 32: three-way conflicts, 12 instead of 4 LDS cycles per store instruction -- 160 of the
+    // 195 conflict cycles per wave the counters show (SQ_LDS_BANK_CONFLICT / SQ_WAVES), the rest being the reads of waves that
+    // straddle two rows.  With consecutive lanes on consecutive q (q = lane % 10, r = 2 (lane / 10)) the stores of a group are 2-dword
+    // runs 100 dwords = 4 banks apart (two-way on the 9th and 10th), and the 8-byte reads are 10 dwords apart: all 64 banks once.
     {
-        const int q = u / 10, r = u - 10 * q;
-        float2 sd = make_float2(1.f, 0.f);
+        const int q = u2 / 10, r = u2 - 10 * q;
+        float2 sd = sd2;
         if (act)
             {
-                if (!(ACQ_ROWS3_DBG && (g.dbg & 4))) sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
-                const float* xr = pre + row * N2 + u;
-                const float* xi = pim + row * N2 + u;
+                if (!ACQ_ROWS3_HOIST_TW && !(ACQ_ROWS3_DBG && (g.dbg & 4))) sd = g.wN2[plan.tw_off[1] + q];  // w_100^q
+                const float* xr = pre + row * N2 + u2;
+                const float* xi = pim + row * N2 + u2;
                 lds_read_pairs10(xr, xi, a);
             }
         __syncthreads();  // every input of this stage has left LDS
@@ -992,12 +1020,28 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
     // ---- stage 3: S = 100, M = 1; r = u; inputs x[r + 100 j]; outputs n2 = r + 100 k with the inter-pass twiddle ----
     if (act)
         {
-            const acq_f32x4 b = (ACQ_ROWS3_DBG && (g.dbg & 4)) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);  // w_N^(k1 r), w_N^(k1 (r + 1))
-            const float2 d = (ACQ_ROWS3_DBG && (g.dbg & 4)) ? make_float2(1.f, 0.f) : g.wN[(size_t)k1 * N2 + 100];                                          // w_N^(100 k1)
+            const acq_f32x4 b = ACQ_ROWS3_HOIST_TW ? b3 : (ACQ_ROWS3_DBG && (g.dbg & (4 | 16))) ? acq_f32x4{1.f, 0.f, 1.f, 0.f} : *reinterpret_cast<const acq_f32x4*>(g.wN + (size_t)k1 * N2 + u);  // w_N^(k1 r), w_N^(k1 (r + 1))
+            const float2 d = ACQ_ROWS3_HOIST_TW ? d3 : (ACQ_ROWS3_DBG && (g.dbg & (4 | 16))) ? make_float2(1.f, 0.f) : g.wN[(size_t)k1 * N2 + 100];                                          // w_N^(100 k1)
             const float* xr = pre + row * N2 + u;
             const float* xi = pim + row * N2 + u;
             lds_read_pairs10(xr, xi, a);
             if (!(ACQ_ROWS3_DBG && (g.dbg & 8))) pk_dft10<INV>(a);
+#if ACQ_ROWS3_DBG
+            if (g.dbg & 16)
+                {
+                    // TIMING MOCK of a rows-LAST pass (columns first): no inter-pass twiddle, |.|^2 of the outputs, 8 bytes per k stored by
+                    // every second cell (a dwell pair's sum written once): 2N bytes per transform instead of 8N
+                    float* gp = reinterpret_cast<float*>(g.Q) + (size_t)(cell >> 1) * N + (size_t)k1 * N2 + u;
+#pragma unroll
+                    for (int k = 0; k < R; k++)
+                        {
+                            const acq_pk2 m = a[k].r * a[k].r + a[k].i * a[k].i;
+                            if (!(cell & 1) || m.x == 1.2345e-33f) *reinterpret_cast<acq_pk2*>(gp + 100 * k) = m;
+                        }
+                }
+            else
+#endif
+            {
             pk_powers10(PkC{psplat(d.x), psplat(d.y)}, tw);
             const PkC bb = {acq_pk2{b.x, b.z}, acq_pk2{b.y, b.w}};
             float2* qp = g.Q + (size_t)cell * N + (size_t)k1 * N2 + u;
@@ -1011,6 +1055,7 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
                     if (!(ACQ_ROWS3_DBG && (g.dbg & 2)) || o.r.x == 1.2345e-33f) *reinterpret_cast<acq_f32x4*>(qp + 100 * k) = acq_f32x4{o.r.x, o.i.x, o.r.y, o.i.y};
 #endif
                 }
+            }
         }
     __syncthreads();  // stage 3 has read the planes: the next group's stage 1 may overwrite them
     }
@@ -1392,6 +1437,36 @@ __global__ __launch_bounds__(ACQ_THREADS, (N1 <= 25 ? ((EPI == ACQ_EPI_MAG2 || E
     __shared__ float sv[2 * (ACQ_THREADS / 64)];
     acq_cols_body<N1, INV, EPI>(plan, Q, out, mag, blockIdx.x, gridDim.x, blockIdx.y, p1, sv);
 }
+
+#if ACQ_ROWS3_DBG
+// TIMING MOCK of a columns-FIRST inverse pass ($GNSSCORR_ACQ_DBG & 32, results meaningless): transform t of a batch = (spectrum t / n_sats,
+// satellite t % n_sats); per column the 25 products A[1000 k + n2] * B[1000 k + n2] (two coalesced arrays), the 25-point inverse DFT in
+// registers, the inter-pass twiddle from a third array, 8N bytes of complex results stored.  Operands, twiddles and results all live in
+// the inter-pass buffer Q (any finite contents do: only the access pattern and the arithmetic are real).
+__global__ __launch_bounds__(ACQ_THREADS, 3) void acq_cols_first_mock_kernel(AcqFftPlan plan, float2* __restrict__ Q, int n_sats, int n_spectra)
+{
+    constexpr int N1 = 25;
+    const int N2 = plan.N2, N = plan.N;
+    const int n2 = blockIdx.x * ACQ_THREADS + threadIdx.x;
+    const int t = blockIdx.y;
+    const int spec = t / n_sats, sat = t - spec * n_sats;
+    const bool active = n2 < N2;
+    const float2* A = Q + (size_t)spec * N;
+    const float2* B = Q + (size_t)(n_spectra + sat) * N;
+    const float2* W = Q + (size_t)(n_spectra + n_sats) * N;
+    float2 v0[N1], v1[N1];
+#pragma unroll
+    for (int k = 0; k < N1; k++) v0[k] = active ? cmul(A[(size_t)k * N2 + n2], B[(size_t)k * N2 + n2]) : make_float2(0.f, 0.f);
+    RegFft<N1, 1, N1, true>::run(v0, v1, plan.w1);
+    float2* res = RegFft<N1, 1, N1, true>::result_in_first ? v0 : v1;
+    if (active)
+        {
+            float2* o = Q + (size_t)(n_spectra + n_sats + 1 + t) * N;
+#pragma unroll
+            for (int k = 0; k < N1; k++) o[(size_t)k * N2 + n2] = cmul_conj(res[k], W[(size_t)k * N2 + n2]);
+        }
+}
+#endif
 
 #ifdef GNSSCORR_EXPERIMENTS  // two measured-slower forms of the inverse transform: a cell kept on its CU, and row / column roles in one launch
 // -----------------------------------------------------------------------------------------------------------------------------
@@ -2508,6 +2583,26 @@ hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const Acq
     AcqMagArgs m;
     std::memset(&m, 0, sizeof m);
     if (mag) m = *mag;
+#if ACQ_ROWS3_DBG
+    {
+        static const int dbg = [] {
+            const char* e = gc_exp_env("GNSSCORR_ACQ_DBG");
+            return e ? std::atoi(e) : 0;
+        }();
+        if ((dbg & 32) && inverse && mag && plan.N1 == 25 && (epilogue == ACQ_EPI_MAG2 || epilogue == ACQ_EPI_MAG2_ACC))
+            {
+                // as many transforms as the real pass (2 per cell), but writing 8N each: the buffer must hold operands + results; the
+                // mock keeps to the first 400 transforms' worth of space by wrapping the result slot
+                const int n_sats = n_cells / m.n_bins, n_spectra = 2 * m.n_bins;
+                const int n_tr = 2 * n_cells;
+                // results wrap inside the buffer: slot index modulo what fits behind the operands
+                (void)n_tr;
+                hipLaunchKernelGGL(acq_cols_first_mock_kernel, dim3(acq_cols_blocks(plan), (unsigned)(2 * n_cells - n_spectra - n_sats - 1)), dim3(ACQ_THREADS), 0, st, plan,
+                    const_cast<float2*>(Q), n_sats, n_spectra);
+                return hipGetLastError();
+            }
+    }
+#endif
     switch (plan.N1)
         {
 #define CASE(K) \

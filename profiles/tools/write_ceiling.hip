@@ -1,0 +1,84 @@
+// write_ceiling.hip -- what the acquisition's inverse ROW pass could reach if only its memory traffic were left: per launch 3280 workgroups of
+// 256 threads, each reading 2 x 40 KB (spectrum rows and code rows; the same 18 MB for everyone: L2 / Infinity Cache hits) and
+// WRITING 40 KB of its own (the inter-pass buffer: 131 MB per launch), 16 bytes per lane, 800-byte runs like acq_rows3_kernel's stores.
+// Variants: stores only / loads + stores, default or nontemporal stores, 4 or 8 workgroups per CU (40 KB or 20 KB of LDS each).
+// Build: hipcc --offload-arch=gfx950 -O3 write_ceiling.hip -o bin/write_ceiling ; run: bin/write_ceiling
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <bool LOADS, bool NT>
+__global__ __launch_bounds__(256) void rows_traffic(const f4* __restrict__ A, const f4* __restrict__ B, f4* __restrict__ Q, int n_groups)
+{
+    extern __shared__ float lds[];
+    const int per_xcd = gridDim.x >> 3;
+    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (group >= n_groups) return;
+    const int p = threadIdx.x;
+    if (p >= 250) return;
+    const int row = p / 50, u = p - row * 50;  // 5 rows of 1000 complex = 500 f4 each; a thread owns f4 number u + 50 k of its row
+    // inputs: rows of 82 spectra x 25 rows (A) and 8 codes x 25 rows (B), picked so that a run of groups shares them
+    const size_t ra = ((size_t)(group * 5 + row) % (82 * 25)) * 500, rb = ((size_t)(group * 5 + row) % (8 * 25)) * 500;
+    f4 acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++)
+        {
+            if (LOADS)
+                {
+                    const f4 a = A[ra + u + 50 * k], b = B[rb + u + 50 * k];
+                    acc[k] = f4{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x, a.z * b.z - a.w * b.w, a.z * b.w + a.w * b.z};
+                }
+            else
+                acc[k] = f4{(float)p, (float)k, (float)group, 1.0f};
+        }
+    f4* q = Q + ((size_t)group * 5 + row) * 500 + u;
+#pragma unroll
+    for (int k = 0; k < 10; k++)
+        {
+            if (NT)
+                __builtin_nontemporal_store(acc[k], q + 50 * k);
+            else
+                q[50 * k] = acc[k];
+        }
+    if (lds[0] == 1.2345e-30f) q[0] = acc[1];  // keeps the dynamic LDS allocation
+}
+
+template <bool LOADS, bool NT>
+static void run(const char* name, const f4* A, const f4* B, f4* Q, int n_groups, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const unsigned grid = (unsigned)((n_groups + 7) / 8 * 8);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((rows_traffic<LOADS, NT>), dim3(grid), dim3(256), lds_bytes, 0, A, B, Q, n_groups);
+    hipDeviceSynchronize();
+    const int reps = 20;
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((rows_traffic<LOADS, NT>), dim3(grid), dim3(256), lds_bytes, 0, A, B, Q, n_groups);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps, mb = (double)n_groups * 40000 / 1e6;
+    std::printf("%-44s lds %5d B/wg: %6.2f us per launch, %6.1f MB written -> %5.2f TB/s of stores\n", name, lds_bytes, us, mb, mb / us / 1e6 * 1e6 / 1e6);
+}
+
+int main()
+{
+    const int n_groups = 3280;  // 656 cells x 25 rows / 5
+    f4 *A, *B, *Q;
+    hipMalloc(&A, (size_t)82 * 25 * 500 * sizeof(f4));
+    hipMalloc(&B, (size_t)8 * 25 * 500 * sizeof(f4));
+    hipMalloc(&Q, (size_t)n_groups * 5 * 500 * sizeof(f4));
+    hipMemset(A, 0, (size_t)82 * 25 * 500 * sizeof(f4));
+    hipMemset(B, 0, (size_t)8 * 25 * 500 * sizeof(f4));
+    for (int lds : {40000, 20000})
+        {
+            run<false, false>("stores only", A, B, Q, n_groups, lds);
+            run<false, true>("stores only, nontemporal", A, B, Q, n_groups, lds);
+            run<true, false>("2 x 40 KB cached loads + stores", A, B, Q, n_groups, lds);
+            run<true, true>("2 x 40 KB cached loads + nontemporal stores", A, B, Q, n_groups, lds);
+        }
+    return 0;
+}

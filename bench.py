@@ -381,30 +381,43 @@ def main():
                 b.set_code(k, np.sign(rng_h.standard_normal(L)).astype(np.float32), hshifts)
                 b.set_input_dev(k, streams[first_ch + k].data_ptr(), n_stream)
                 recs.append([gnsscorr.epoch_params(e * n_len, 0.1, 1e-3, 0.3, float(np.float32(step_chips)), n_len) for e in range(n_ep)])
+            b.set_nominal_length(n_len)
+            if os.environ.get("BENCH_SLICES"):
+                b.set_slices(int(os.environ["BENCH_SLICES"]))
             d_p = torch.from_numpy(gnsscorr.epoch_params_array(recs).view(np.uint8)).to(dev)
             d_o = torch.zeros(n_ch * n_ep * n_taps, 2, device=dev, dtype=torch.float32)
             hb.append((b, n_ep, d_p, d_o, n_ch * n_ep * n_len))
         add_group(0, 16, 3, 1023, N_EPOCH, 1.023e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
         add_group(16, 8, 5, 8184, 4 * N_EPOCH, 2.046e6 / FS, np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32))
         add_group(24, 8, 3, 2046, N_EPOCH, 2.046e6 / FS, np.array([-0.5, 0.0, 0.5], np.float32))
+        # the three signal groups are independent engines: each launches on a stream of its own (as a receiver's per-signal tracking
+        # groups would), so that the tail of one group's launch overlaps the head of another's; BENCH_HYBRID_ONE_STREAM=1: one stream
+        one_stream = os.environ.get("BENCH_HYBRID_ONE_STREAM") == "1"
+        hstreams = [tstream] + ([] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(2)])
         def hybrid_step():
-            for b, n_ep, d_p, d_o, _ in hb:
-                b.run_dev(n_ep, d_p.data_ptr(), d_o.data_ptr(), stream)
+            for k_, (b, n_ep, d_p, d_o, _) in enumerate(hb):
+                b.run_dev(n_ep, d_p.data_ptr(), d_o.data_ptr(), hstreams[k_ % len(hstreams)].cuda_stream)
         for _ in range(2):
             hybrid_step()
         torch.cuda.synchronize()
         h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        h0.record()
+        h0.record(tstream)
+        for hs in hstreams[1:]:
+            hs.wait_event(h0)
         for _ in range(args.steps):
             hybrid_step()
-        h1.record()
+        for hs in hstreams[1:]:
+            je = torch.cuda.Event()
+            je.record(hs)
+            tstream.wait_event(je)
+        h1.record(tstream)
         torch.cuda.synchronize()
         hyb_ms = h0.elapsed_time(h1) / args.steps
         hyb_samples = sum(g[4] for g in hb)
         res = {"value": hyb_samples / (hyb_ms * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_step": hyb_ms,
             "hbm_gbps": 8.0 * hyb_samples / (hyb_ms * 1e-3) / 1e9, "realtime_factor_32ch": hyb_samples / (hyb_ms * 1e-3) / (32 * FS),
             "note": "one GPU's share of the 256-channel hybrid: 16 GPS L1 C/A (3 taps) + 8 Galileo E1 (5 taps, L = 8184, 4 ms) + 8 BeiDou B1I "
-                    "(3 taps, L = 2046), 25 Msps, distinct IQ buffer per channel, three launches per step",
+                    "(3 taps, L = 2046), 25 Msps, distinct IQ buffer per channel, three launches per step%s" % (" on one stream" if one_stream else ", one stream per signal group"),
             "roofline": mode_roofline(vceil, [(hb[0][4], 8.0, "gps_l1_3tap_f32", 1.0), (hb[1][4], 8.0, "galileo_5tap_f32", 1.0),
                 (hb[2][4], 8.0, "gps_l1_3tap_f32", 1.0)], hyb_ms)}
         for g in hb:
@@ -600,6 +613,9 @@ def main():
                 bg.set_input_dev(ch, streams[ch].data_ptr(), n_stream)
                 grecs.append([gnsscorr.epoch_params(k * n_gal, 0.1, float(np.float32(2 * np.pi * 1000.0 / FS)), 0.3, float(np.float32(2.046e6 / FS)), n_gal)
                     for k in range(e_gal)])
+            bg.set_nominal_length(n_gal)  # the engine sizes a launch's code window by it (two half-period slices for L = 8184)
+            if os.environ.get("BENCH_SLICES"):
+                bg.set_slices(int(os.environ["BENCH_SLICES"]))
             d_gp = torch.from_numpy(gnsscorr.epoch_params_array(grecs).view(np.uint8)).to(dev)
             d_go = torch.zeros(N_CHANNELS * e_gal * 5, 2, device=dev, dtype=torch.float32)
             for _ in range(2):

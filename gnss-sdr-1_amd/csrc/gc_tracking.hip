@@ -55,6 +55,7 @@ struct gc_trk_batch
     gc_ctx_ref ctx_ref;
     int n_channels = 0, n_taps = 0, max_code_len = 0, mode = TRK_MODE_PLAIN;
     int lds_table_floats = 0;
+    bool lds_sizing = true;  // size a launch's LDS by what a slice touches (gc_trk_batch_set_slices(b, -1) turns it off: A/B timing)
     int nominal_len = 0;
     int iq_format = GC_IQ_F32;
     int forced_slices = 0;
@@ -338,8 +339,9 @@ gc_status gc_trk_batch_set_nominal_length(gc_trk_batch* b, int n_samples)
 
 gc_status gc_trk_batch_set_slices(gc_trk_batch* b, int n_slices)
 {
-    GC_REQUIRE(b && n_slices >= 0 && n_slices <= 1024, "gc_trk_batch_set_slices: bad argument");
-    b->forced_slices = n_slices;
+    GC_REQUIRE(b && n_slices >= -1 && n_slices <= 1024, "gc_trk_batch_set_slices: bad argument");
+    b->lds_sizing = n_slices >= 0;
+    b->forced_slices = n_slices > 0 ? n_slices : 0;
     return GC_OK;
 }
 
@@ -365,7 +367,42 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
         }
     gc_status s = batch_sync_chans(b, st);
     if (s != GC_OK) return s;
-    const int n_slices = pick_slices(b, n_epochs, max_len > 0 ? max_len : b->nominal_len);
+    int n_slices = pick_slices(b, n_epochs, max_len > 0 ? max_len : b->nominal_len);
+    // LDS of the launch: what one slice of a nominal epoch touches, not the capacity of the longest code (Galileo E1: 33 KB per
+    // workgroup = 4 waves per SIMD; half a period per slice: 17 KB = 8).  Known on the host: the nominal window length, the code
+    // lengths, the tap shifts; a code period per nominal window gives the chips per sample.  A record that exceeds the bound (a code
+    // step far off nominal, a longer window) is served by the kernel from the whole table in LDS when it fits the launch's LDS, from
+    // global memory otherwise (trk_epoch, GTAB): the bound decides speed, never results.
+    int lds_floats = b->lds_table_floats;
+    const int len = max_len > 0 ? max_len : b->nominal_len;
+    if (len >= 4096 && !b->sc16 && b->lds_sizing)
+        {
+            int l_max = 0;
+            float spread = 0.0f;
+            for (int i = 0; i < b->n_channels; i++)
+                {
+                    l_max = std::max(l_max, b->h_chans[i].code_len);
+                    float lo = b->h_chans[i].shifts[0], hi = lo;
+                    for (int t = 1; t < b->n_taps; t++)
+                        {
+                            lo = std::min(lo, b->h_chans[i].shifts[t]);
+                            hi = std::max(hi, b->h_chans[i].shifts[t]);
+                        }
+                    spread = std::max(spread, hi - lo);
+                }
+            const int per_chip = b->complex_codes ? 2 : 1;
+            const int window_target = 4096;  // floats of LDS per workgroup that still leave 8 waves per SIMD (9 workgroups of ~17 KB per CU)
+            if (b->forced_slices == 0 && l_max + 64 > window_target + 128 && b->mode == TRK_MODE_PLAIN)
+                n_slices = std::max(n_slices, (l_max + window_target - 1) / window_target);
+            if (n_slices > 1)
+                {
+                    const int chunks = (len + 16 + 511) / 512;  // + the alignment lead-in of at most 8 sample pairs
+                    const int cps = (chunks + n_slices - 1) / n_slices;
+                    const double chips_per_sample = (double)l_max / (double)len;
+                    const int need = per_chip * ((int)std::ceil((double)cps * 512.0 * chips_per_sample * 1.002 + (double)spread) + 64);
+                    if (need < lds_floats) lds_floats = (need + 63) & ~63;
+                }
+        }
     if (n_slices > 1)
         {
             size_t need = (size_t)b->n_channels * n_epochs * n_slices * b->n_taps;
@@ -399,7 +436,7 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
                 }
         }
     hipError_t e = trk_launch(b->n_taps, b->mode, b->iq_format, st, b->d_chans, dev_params, static_cast<float2*>(dev_out), b->d_partial,
-        b->n_channels, n_epochs, n_slices, b->lds_table_floats, true);
+        b->n_channels, n_epochs, n_slices, lds_floats, true);
     if (e != hipSuccess)
         {
             cancel_all();

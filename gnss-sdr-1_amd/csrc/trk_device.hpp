@@ -540,7 +540,10 @@ static __device__ __forceinline__ void trk_fill_resident(float* lds, const float
         }
 }
 
-template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF, bool CHIPS = false, bool NT = (TRK_NT != 0), bool WHOLE = true>
+// GTAB: the launch may have been given LESS LDS than the whole code table needs (the batched kernel sizes its window by what a slice of
+// a nominal epoch touches: more workgroups per CU for long codes).  A record whose chips neither fit that window nor allow the whole
+// table in LDS then reads the table from global memory with the modulo form (slow, correct, rare: a code step far off the nominal one)
+template <int NTAPS, bool HDR, bool HDC, int FMT, bool CC = false, bool SC16 = false, int THREADS = TRK_THREADS, bool DATA = false, int PF = TRK_PF, bool CHIPS = false, bool NT = (TRK_NT != 0), bool WHOLE = true, bool GTAB = false>
 static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_epoch_params& p, int slice, int n_slices,
     int lds_table_floats, float* lds, int align_pairs = TRK_ALIGN_PAIRS, bool resident = false)
 {
@@ -686,6 +689,7 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
     constexpr int NACC = NTAPS + (DATA ? 1 : 0);
     float* table2 = DATA ? table + (windowed ? (int)span_ll : L) : nullptr;
     const GC_GLOBAL float* code2 = (const GC_GLOBAL float*)cd.code2;
+    const bool table_fits = !GTAB || (long long)L * (long long)(sizeof(chip_t) / sizeof(float)) * (DATA ? 2 : 1) <= (long long)lds_table_floats;
     if (resident && !CC)
         {
             // the doubled image is in place: address the window inside it (chip - lo + cbase < 2 L + pad), or fall back to its
@@ -718,7 +722,7 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
                         }
                 }
         }
-    else
+    else if (table_fits)
         {
             for (int k = tid; k < L; k += THREADS)
                 {
@@ -742,8 +746,10 @@ static __device__ __forceinline__ float2 trk_epoch(const TrkChan& cd, const gc_e
         }
     else if (windowed)
         trk_loop<NTAPS, HDR, HDC, true, FMT, CC, SC16, THREADS, DATA, PF, NT, WHOLE>(base, table, a, N, V, c0, c1, lo, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2, lc0, lc1, pre0, pre1);
-    else
+    else if (table_fits)
         trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA, PF, NT, WHOLE>(base, table, a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, table2, lc0, lc1, pre0, pre1);
+    else if constexpr (GTAB)
+        trk_loop<NTAPS, HDR, HDC, false, FMT, CC, SC16, THREADS, DATA, PF, NT, WHOLE>(base, reinterpret_cast<const float*>(cd.code), a, N, V, c0, c1, 0, L, step, rem, rate, shifts, tap_delay, theta0, dtheta, drate, lnmod, accr, acci, cd.code2, lc0, lc1, pre0, pre1);
 
     // ---- reduction: lanes -> wave (shuffles) -> workgroup (LDS) ----
     __syncthreads();  // the code window has been consumed by every thread

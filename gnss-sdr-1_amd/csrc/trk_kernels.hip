@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TRK_THREADS, CHIPS ? TRK_CHIPS_WAVES : TRK_WAVES) v
 
     const TrkChan cd = chans[ch];
     const gc_epoch_params p = params[job];
-    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC, SC16, TRK_THREADS, false, TRK_PF, CHIPS>(cd, p, slice, n_slices, lds_table_floats, lds, align_pairs);
+    const float2 r = trk_epoch<NTAPS, HDR, HDC, FMT, CC, SC16, TRK_THREADS, false, TRK_PF, CHIPS, (TRK_NT != 0), true, !CHIPS>(cd, p, slice, n_slices, lds_table_floats, lds, align_pairs);
     if (threadIdx.x < NTAPS)
         {
             if (n_slices == 1)

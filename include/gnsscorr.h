@@ -276,7 +276,12 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
     float* host_out);
 /* Engine tuning (no reference counterpart).  Nominal integration length: lets
  * gc_trk_batch_run_dev pick how many slices to cut an epoch into when the
- * batch alone would not fill the GPU.  set_slices(0) = automatic. */
+ * batch alone would not fill the GPU, and size the LDS code window of a launch by what
+ * one slice of such an epoch touches (long codes: Galileo E1's 8184 samples are cut in
+ * two so that a workgroup holds half the table).  Results never depend on it: a record
+ * outside the bound is served from the whole table.  set_slices(0) = automatic;
+ * set_slices(-1) = automatic slicing by load only, the window sized for the longest code
+ * (the behaviour before round 4; A/B timing). */
 gc_status gc_trk_batch_set_nominal_length(gc_trk_batch* b, int n_samples);
 gc_status gc_trk_batch_set_slices(gc_trk_batch* b, int n_slices);
 

@@ -1,7 +1,6 @@
-for q in ${QS:-96 90 74 66 50 135 170}; do
-  GNSSCORR_ACQ_Q_MB=$q python bench.py --no-shared --no-cpu > gpurun_out/sw_$q.json 2>/dev/null
-  python - <<PY
-import json
-d=json.loads(open("gpurun_out/sw_$q.json").read().strip().splitlines()[-1]); print($q, d["acquisition"]["ms_per_search"])
-PY
+# search time against the inter-pass buffer budget ($GNSSCORR_ACQ_Q_MB: satellites per batch); run on the GPU box
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for q in 35 70 100 140 200 270 540; do
+  GNSSCORR_ACQ_Q_MB=$q python3 $R/profiles/tools/acq_time.py --label "q$q" 2>&1 | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['label'], 'cold %.4f steady %.4f found %s' % (j['cold_ms'], j['steady_ms'], j['found']))"
 done

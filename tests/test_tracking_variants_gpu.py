@@ -48,6 +48,36 @@ def test_galileo_e1_five_taps_4ms(gctx, oracle):
         assert rel_err(got_sliced[k], refs[k], 2) <= TOL
 
 
+def test_launch_window_smaller_than_the_code_table(gctx, oracle):
+    """A launch's LDS code window is sized by what one slice of a NOMINAL epoch touches (L = 8184, N = 100000: two slices, ~4.3 k floats
+    instead of 8248), so a record outside that bound has neither its window nor the whole table in LDS and reads the table from global
+    memory (trk_epoch, GTAB).  One batch of four records on one channel: a nominal one (windowed), one whose code step is 2.6 x nominal
+    (its slices touch ~11000 chips: global path), one with a negative step (not monotone: global path), and a nominal one again; all
+    against the oracle, and equal to what the pre-sizing launch (set_slices(-1): whole table in LDS) gives."""
+    import gnsscorr
+    e1b = np.load(os.path.join(G, "galileo_e1_codes.npz"))["e1b"]
+    code = oracle.galileo_e1_sinboc11(e1b[3])
+    fs, n = 25_000_000, 100000
+    sig, truth = synth_stream([code], fs, 4 * n + 64, seed=1404, cn0_db_hz=(45.0, 45.0), chip_rate=2 * 1.023e6)
+    shifts = np.array([-1.2, -0.3, 0.0, 0.3, 1.2], np.float32)
+    nominal = open_loop_params(truth[0], fs, 8184, n, 4)
+    steps = [float(nominal[0]["code_step"]), 2.6 * float(nominal[1]["code_step"]), -float(nominal[2]["code_step"]), float(nominal[3]["code_step"])]
+    recs, refs = [], []
+    for k, p in enumerate(nominal):
+        off = p["sample_offset"] + (3 if k == 1 else 0)
+        recs.append(gnsscorr.epoch_params(off, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), steps[k], n))
+        refs.append(oracle.multicorrelator(sig[off:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], np.float32(steps[k]), n))
+    got = _batch_one(gctx, sig, code, shifts, recs)
+    old = _batch_one(gctx, sig, code, shifts, recs, slices=-1)
+    scale = abs(refs[0][2])
+    assert scale > 0.5 * truth[0]["amp"] * n
+    for k in range(4):
+        assert np.max(np.abs(got[k] - refs[k])) <= TOL * scale, k
+        assert np.max(np.abs(old[k] - refs[k])) <= TOL * scale, k
+    # the two nominal records are on the correlation peak; the others decorrelate (wrong chip rate / direction)
+    assert abs(got[3][2]) > 0.5 * truth[0]["amp"] * n and abs(got[1][2]) < 0.1 * abs(got[0][2]) and abs(got[2][2]) < 0.1 * abs(got[0][2])
+
+
 def test_beidou_b1i_three_taps(gctx, oracle):
     import gnsscorr
     code = oracle.beidou_b1i_code(6).astype(np.float32)

@@ -3,6 +3,7 @@
 #define ACQ_KERNELS_H
 #include "gnsscorr.h"
 #include <hip/hip_runtime.h>
+#include "acq_phase_segments.h"
 
 #define ACQ_MAX_FACTORS 12
 #define ACQ_MAX_N1 64
@@ -83,9 +84,10 @@ bool acq_inv_fusable(const AcqFftPlan& plan);
 hipError_t acq_launch_inv_fused(hipStream_t st, const AcqFftPlan& plan, int n_sats, int n_bins, int n_tr, bool accumulate, const float2* A, const float2* B,
     const float2* wN2, const float2* wN, const AcqMagArgs& mag, int n_cus);
 
-// phase_scratch[bin][n] = float32 running sum of phase_inc[bin] (volk_gnsssdr_s32f_sincos_32fc, n_bins * N floats, natural order);
-// out[bin][(n % N1) * N2 + n / N1] = (cos, sin) of it: the table in the row-permuted layout the forward row pass reads
-hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float* phase_scratch, float2* out, int n_bins, const AcqFftPlan& plan);
+// out[bin][(n % N1) * N2 + n / N1] = (cos, sin) of the float32 running phase of sample n (volk_gnsssdr_s32f_sincos_32fc): the table in the
+// row-permuted layout the forward row pass reads, in one kernel from the rows' arithmetic-progression segments (acq_phase_segments.h):
+// seg_off[bin] .. seg_off[bin + 1] index `segs`
+hipError_t acq_launch_wipeoff_segments(hipStream_t st, const AcqPhaseSeg* segs, const int* seg_off, float2* out, int n_bins, const AcqFftPlan& plan);
 
 // cshort / cbyte input block -> float complex (n samples)
 hipError_t acq_launch_convert(hipStream_t st, int iq_format, const void* in, float2* out, int n);

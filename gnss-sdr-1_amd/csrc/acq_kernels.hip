@@ -1948,55 +1948,44 @@ __global__ __launch_bounds__(256) void acq_permute_tiled_kernel(const float2* __
 }
 
 // ---- Doppler wipe-off table (pcps_acquisition::update_local_carrier, :296-310) ----
-// volk_gnsssdr_s32f_sincos_32fc_generic: _phase += phase_inc in float32, out = (cosf, sinf)
-// Two kernels, each writing a buffer it does not read: the running phases (one lane per bin: the float32 sum is sequential by
-// definition) go to a scratch array in natural order, then (cos, sin) of every phase is stored AT ITS ROW-PERMUTED POSITION
-// P[bin][a][b] = wipe[bin][a + N1 b] of the table the forward row pass reads.  (Rounds 1-3 built the table in natural order, permuted
-// it into a staging buffer and copied it back device-to-device; round 3 also parked the phases inside the table.  Nothing is built in
-// place any more and no copy engine takes part in a set-up call.)
-__global__ void acq_wipeoff_phase_kernel(const float* __restrict__ phase_inc, float* __restrict__ phase, int n_bins, int N)
-{
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= n_bins) return;
-    const float inc = phase_inc[bin];
-    float p = 0.0f;
-    float* row = phase + (size_t)bin * N;
-    for (int i = 0; i < N; i++)
-        {
-            row[i] = p;
-            p = p + inc;  // sequential float32 running sum, exactly as the reference
-        }
-}
-// one workgroup per (tile of 64 consecutive b, bin): reads the contiguous phases n = N1 b0 .. N1 (b0 + 64) - 1, stores 64-element
-// runs of each of the N1 permuted rows (the gather of acq_permute_tiled_kernel with sincosf on the way through LDS)
-__global__ __launch_bounds__(256) void acq_wipeoff_sincos_perm_kernel(const float* __restrict__ phase, float2* __restrict__ out, int N, int N1, int N2)
+// volk_gnsssdr_s32f_sincos_32fc_generic: _phase += phase_inc in float32, out = (cosf, sinf); stored AT ITS ROW-PERMUTED POSITION
+// P[bin][a][b] = wipe[bin][a + N1 b] of the table the forward row pass reads.  (Rounds 1-3 built the table in natural order from a
+// sequential phase kernel, permuted it into a staging buffer and copied it back device-to-device; nothing is built in place any more,
+// there is no scratch array and no copy engine takes part in a set-up call.)
+// The whole table in ONE kernel: the running phase of sample n comes from the bin's arithmetic-progression segments
+// (acq_phase_segments.h: the float32 running sum in closed form, bit for bit), so every sample is independent -- no sequential lane
+// per bin (0.56 ms for N = 25000), no phase scratch.  seg_off[bin] .. seg_off[bin + 1]: the bin's segments, sorted by first sample.
+__global__ __launch_bounds__(256) void acq_wipeoff_segments_kernel(const AcqPhaseSeg* __restrict__ segs, const int* __restrict__ seg_off,
+    float2* __restrict__ out, int N, int N1, int N2)
 {
     extern __shared__ float2 tile[];  // [ACQ_PERM_TB * N1]
     const int bin = blockIdx.y;
     const int b0 = blockIdx.x * ACQ_PERM_TB;
     const int nb = min(ACQ_PERM_TB, N2 - b0);
     const int base = N1 * b0, count = N1 * nb;
+    const AcqPhaseSeg* sg = segs + seg_off[bin];
+    const int n_segs = seg_off[bin + 1] - seg_off[bin];
     for (int i = threadIdx.x; i < count; i += 256)
         {
-            float s, c;
-            sincosf(phase[(size_t)bin * N + base + i], &s, &c);
-            tile[i] = make_float2(c, s);
+            const int n = base + i;
+            int lo = 0, hi = n_segs - 1;
+            while (lo < hi)
+                {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (sg[mid].i0 <= n)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+            const float ph = (float)(sg[lo].p0 + (double)(n - sg[lo].i0) * sg[lo].d);  // exact in double, representable in float
+            float sn, cs;
+            sincosf(ph, &sn, &cs);
+            tile[i] = make_float2(cs, sn);
         }
     __syncthreads();
     const int j = threadIdx.x & (ACQ_PERM_TB - 1);
     for (int a = threadIdx.x / ACQ_PERM_TB; a < N1; a += 256 / ACQ_PERM_TB)
         if (j < nb) out[(size_t)bin * N + (size_t)a * N2 + b0 + j] = tile[a + N1 * j];
-}
-// N1 too large for the tile: one thread per element, scattered 8-byte stores (set-up only)
-__global__ void acq_wipeoff_sincos_scatter_kernel(const float* __restrict__ phase, float2* __restrict__ out, int N, int N1, int N2, size_t total)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const size_t bin = i / (size_t)N;
-    const int n = (int)(i - bin * (size_t)N);
-    float s, c;
-    sincosf(phase[i], &s, &c);
-    out[bin * (size_t)N + (size_t)(n % N1) * N2 + n / N1] = make_float2(c, s);
 }
 
 // ---- integer input samples -> gr_complex (volk_gnsssdr_16ic_convert_32fc at the head of acquisition_core,
@@ -2630,24 +2619,12 @@ hipError_t acq_launch_cols(hipStream_t st, bool inverse, int epilogue, const Acq
         }
 }
 
-hipError_t acq_launch_wipeoff(hipStream_t st, const float* phase_inc, float* phase_scratch, float2* out, int n_bins, const AcqFftPlan& plan)
+hipError_t acq_launch_wipeoff_segments(hipStream_t st, const AcqPhaseSeg* segs, const int* seg_off, float2* out, int n_bins, const AcqFftPlan& plan)
 {
-    const int N = plan.N;
-    hipLaunchKernelGGL(acq_wipeoff_phase_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, st, phase_inc, phase_scratch, n_bins, N);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
     const size_t lds = sizeof(float2) * ACQ_PERM_TB * (size_t)plan.N1;
-    if (lds <= 48 * 1024)
-        {
-            dim3 grid((plan.N2 + ACQ_PERM_TB - 1) / ACQ_PERM_TB, n_bins);
-            hipLaunchKernelGGL(acq_wipeoff_sincos_perm_kernel, grid, dim3(256), lds, st, phase_scratch, out, N, plan.N1, plan.N2);
-        }
-    else
-        {
-            const size_t total = (size_t)n_bins * N;
-            hipLaunchKernelGGL(acq_wipeoff_sincos_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, phase_scratch, out, N, plan.N1,
-                plan.N2, total);
-        }
+    if (lds > 48 * 1024) return hipErrorInvalidValue;  // N1 <= 50 in every plan acq_plan_make produces: 25.6 KB
+    dim3 grid((plan.N2 + ACQ_PERM_TB - 1) / ACQ_PERM_TB, n_bins);
+    hipLaunchKernelGGL(acq_wipeoff_segments_kernel, grid, dim3(256), lds, st, segs, seg_off, out, plan.N, plan.N1, plan.N2);
     return hipGetLastError();
 }
 

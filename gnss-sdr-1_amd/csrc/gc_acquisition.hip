@@ -51,7 +51,9 @@ struct gc_acq
     unsigned* d_part_cnt = nullptr;   // and its ticket counters
     std::vector<char> code_set;
     int64_t freq_offset_hz = 0;  // d_old_freq: intermediate frequency / GLONASS FDMA channel offset
-    float* d_inc = nullptr;       // phase increments of the table being built [n_bins_alloc]
+    AcqPhaseSeg* d_segs = nullptr;  // closed-form segments of the rows' running phases (acq_phase_segments.h) [seg_cap]
+    int* d_seg_off = nullptr;       // [n_bins_alloc + 1]
+    size_t seg_cap = 0;
     // the wipe-off tables hold what freq_offset_hz / the step-two centre say: cleared before a rebuild starts, set when it has
     // completed; a search on tables in an unknown state is refused (GC_ERR_STATE) instead of run
     bool wipe_valid = false, wipe2_valid = false;
@@ -123,7 +125,8 @@ static void acq_release(gc_acq* a)
     (void)hipFree(a->d_wN2);
     (void)hipFree(a->d_wipe_main);
     (void)hipFree(a->d_wipe2);
-    (void)hipFree(a->d_inc);
+    (void)hipFree(a->d_segs);
+    (void)hipFree(a->d_seg_off);
     (void)hipFree(a->d_codes);
     (void)hipFree(a->d_xw);
     (void)hipFree(a->d_X);
@@ -150,15 +153,35 @@ static void acq_release(gc_acq* a)
 // The wipe-off tables are kept in the row-permuted layout the forward row pass reads (P[bin][a][b] = wipe[bin][a + N1 * b]): the
 // product x * wipeoff[bin] (pcps_acquisition.cc:717) is then the two-operand load of that pass -- A = the table, B = the permuted
 // input block, shared by every bin -- instead of a kernel of its own that writes and re-reads n_bins x N products per dwell.
-// A table is built out of place in two kernels (acq_launch_wipeoff): running phases into the inter-pass buffer d_Q (idle during a
-// set-up call: every caller has flushed the held-back passes), then (cos, sin) at the permuted positions of the table.  The caller
-// holds the context mutex.
+// A table is built out of place by ONE kernel in which every sample is independent: the float32 running phase of each row in closed form
+// (acq_phase_segments.h, ~30 arithmetic-progression segments per row, computed here on the host; 25000 dependent additions on one
+// lane per bin took 0.56 ms), (cos, sin) stored at the permuted position.  No scratch array, no device-to-device copy, no allocation
+// in a set-up call unless a pathological increment needs more segments than the buffer holds.  The caller holds the context mutex.
 static hipError_t acq_build_wipeoffs(gc_acq* a, const std::vector<float>& inc, float2* table, hipStream_t st)
 {
     const int n = (int)inc.size();
-    hipError_t e = hipMemcpyAsync(a->d_inc, inc.data(), sizeof(float) * n, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = acq_launch_wipeoff(st, a->d_inc, reinterpret_cast<float*>(a->d_Q), table, n, a->plan);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);  // `inc` may go out of scope; d_Q is free again
+    std::vector<AcqPhaseSeg> segs;
+    std::vector<int> off(n + 1, 0);
+    for (int d = 0; d < n; d++)
+        {
+            acq_phase_segments(inc[d], (int)a->fft_size, segs);
+            off[d + 1] = (int)segs.size();
+        }
+    hipError_t e = hipSuccess;
+    if (segs.size() > a->seg_cap)
+        {
+            e = hipStreamSynchronize(st);
+            (void)hipFree(a->d_segs);
+            a->d_segs = nullptr;
+            a->seg_cap = 0;
+            if (e == hipSuccess) e = hipMalloc(&a->d_segs, segs.size() * sizeof(AcqPhaseSeg));
+            if (e != hipSuccess) return e;
+            a->seg_cap = segs.size();
+        }
+    e = hipMemcpyAsync(a->d_segs, segs.data(), sizeof(AcqPhaseSeg) * segs.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(a->d_seg_off, off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = acq_launch_wipeoff_segments(st, a->d_segs, a->d_seg_off, table, n, a->plan);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host vectors go out of scope
     return e;
 }
 
@@ -287,7 +310,9 @@ gc_status gc_acq_create(gc_ctx* ctx, const gc_acq_conf* conf, int n_sats, gc_acq
                 }
         }
     ACQ_TRY(hipMalloc(&a->d_Q, (a->q_stride ? 2 : 1) * q_cells * N * sizeof(float2)));
-    ACQ_TRY(hipMalloc(&a->d_inc, (size_t)a->n_bins_alloc * sizeof(float)));
+    a->seg_cap = (size_t)a->n_bins_alloc * 128;
+    ACQ_TRY(hipMalloc(&a->d_segs, a->seg_cap * sizeof(AcqPhaseSeg)));
+    ACQ_TRY(hipMalloc(&a->d_seg_off, ((size_t)a->n_bins_alloc + 1) * sizeof(int)));
     ACQ_TRY(hipMalloc(&a->d_grid, (size_t)n_sats * a->n_bins_alloc * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_tmp, (size_t)n_sats * N * sizeof(float)));
     ACQ_TRY(hipMalloc(&a->d_blkv, (size_t)n_sats * a->n_bins_alloc * a->n_blocks * sizeof(float)));

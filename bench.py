@@ -161,12 +161,14 @@ def cpu_baseline_threads(codes_np, shifts, sample_sig, sample_recs, budget_s, n_
 
 
 def load_valu_ceilings():
-    """profiles/r03_valu_ceilings.json (profiles/tools/valu_ceiling.py): VALU-issue ceiling of each kernel's interior loop from its
+    """profiles/r04_valu_ceilings.json (profiles/tools/valu_ceiling.py): VALU-issue ceiling of each kernel's interior loop from its
     disassembled instruction mix x the issue rates measured on the chip x 1024 SIMDs at the nominal clock."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03_valu_ceilings.json")))["kernels"]
-    except Exception:
-        return {}
+    for name in ("r04_valu_ceilings.json", "r03_valu_ceilings.json"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+        except Exception:
+            continue
+    return {}
 
 
 def mode_roofline(ceil, parts, ms, serial_us_per_unit=None):
@@ -195,8 +197,8 @@ def mode_roofline(ceil, parts, ms, serial_us_per_unit=None):
     out = {"bound": "hbm" if t_hbm >= t_valu else "valu", "achieved": achieved, "unit": "Msamples/s",
         "ceiling": n / t_bound / 1e6 if t_bound > 0 else None, "frac": t_bound / (ms * 1e-3),
         "hbm_frac": t_hbm / (ms * 1e-3), "valu_frac": None if missing else t_valu / (ms * 1e-3),
-        "ceiling_source": "max(HBM: bytes / 8 TB/s, VALU: profiles/r03_valu_ceilings.json = interior-loop instruction mix (hipcc -S) x "
-                          "profiles/r02_valu_issue_rates.txt x 1024 SIMDs x 2.4 GHz) per launch, summed; counters: profiles/r03_trk_sq_counters.json"}
+        "ceiling_source": "max(HBM: bytes / 8 TB/s, VALU: profiles/r04_valu_ceilings.json = interior-loop instruction mix (hipcc -S) x "
+                          "profiles/r02_valu_issue_rates.txt x 1024 SIMDs x 2.4 GHz) per launch, summed; counters: profiles/r04_trk_sq_counters.json"}
     if serial_us_per_unit:
         out["bound"] = out["bound"] + " + one-lane loop maths"
         out["serial_us"] = serial_us_per_unit
@@ -813,7 +815,7 @@ def main():
                 floor_us_per_ms = max(fl[0], fl[1] / 4.0, fl[2])
                 share_roof = {"bound": "valu + one-lane loop maths", "achieved": ms_total / share_ms, "ceiling": 1000.0 / floor_us_per_ms, "unit": "x real time",
                     "frac": (1000.0 / floor_us_per_ms and (ms_total / share_ms) / (1000.0 / floor_us_per_ms)),
-                    "ceiling_source": "per code period: samples / (VALU ceiling of one CU, profiles/r03_valu_ceilings.json) + 2.6 us of one-lane loop maths; "
+                    "ceiling_source": "per code period: samples / (VALU ceiling of one CU, profiles/r04_valu_ceilings.json) + 2.6 us of one-lane loop maths; "
                                       "the slowest of the three concurrent engines sets the floor"}
             extra["closed_loop_cfg5_share"] = {"channels": 32, "ms_of_signal": ms_total, "ms": share_ms, "realtime_factor": ms_total / share_ms, "roofline": share_roof,
                 "note": "16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I channels x 25 Msps in closed loop, three engines on three "

@@ -3,7 +3,7 @@
 on the chip (profiles/r02_valu_issue_rates.txt, cycles of the nominal 2.4 GHz clock per wave-instruction on one SIMD at 8 waves per
 SIMD) x 1024 SIMDs.  Runs in the build container (hipcc -S, no GPU):
 
-    python profiles/tools/valu_ceiling.py            ->  profiles/r03_valu_ceilings.json
+    python profiles/tools/valu_ceiling.py            ->  profiles/r04_valu_ceilings.json
 
 For every kernel named below it finds the interior loop (the innermost loop that contains the 16-byte global loads of the IQ
 stream), counts its instructions by issue class, and reports
@@ -140,7 +140,7 @@ def main():
         res["kernels"][key] = r
         print("%-28s %3d VALU / iteration (%.1f per sample), %.0f cycles -> ceiling %.0f Msamples/s  %s" % (key, r["valu_instructions"], r["valu_instructions_per_sample"],
             r["cycles_per_iteration"], r["ceiling_msamples_s"], r["mix"]))
-    json.dump(res, open(os.path.join(ROOT, "profiles", "r03_valu_ceilings.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "profiles", "r04_valu_ceilings.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

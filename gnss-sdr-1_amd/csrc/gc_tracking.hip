@@ -358,7 +358,7 @@ static std::vector<gc_stream*> batch_streams(const gc_trk_batch* b)
 // The reader slots are reserved BEFORE the residency check and the enqueue, so a push on the producer's thread cannot evict
 // what this launch was validated for (gc_reader_table.h).
 static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_params* dev_params, void* dev_out,
-    hipStream_t st, int max_len, const std::vector<uint64_t>* floors = nullptr, const std::vector<uint64_t>* ends = nullptr)
+    hipStream_t st, int max_len, const std::vector<uint64_t>* floors = nullptr, const std::vector<uint64_t>* ends = nullptr, float max_step = 0.0f)
 {
     for (int i = 0; i < b->n_channels; i++)
         {
@@ -399,9 +399,14 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
                 {
                     const int chunks = (len + 16 + 511) / 512;  // + the alignment lead-in of at most 8 sample pairs
                     const int cps = (chunks + n_slices - 1) / n_slices;
-                    const double chips_per_sample = (double)l_max / (double)len;
+                    // chips per sample: the largest |code step| of the records when the caller's parameter array is on the host
+                    // (gc_trk_batch_run), else one code period per nominal window (device-resident records: a batch whose windows
+                    // span several code periods should state so with gc_trk_batch_set_slices(b, -1))
+                    const double chips_per_sample = max_step > 0.0f ? (double)max_step : (double)l_max / (double)len;
                     const int need = per_chip * ((int)std::ceil((double)cps * 512.0 * chips_per_sample * 1.002 + (double)spread) + 64);
-                    if (need < lds_floats) lds_floats = (need + 63) & ~63;
+                    // (a table that fits the 8-waves budget whole is left whole: nothing to gain, and windows of several code periods keep
+                    // the LDS modulo path)
+                    if (need < lds_floats && lds_floats > window_target + 128) lds_floats = std::max((need + 63) & ~63, 1024);
                 }
         }
     if (n_slices > 1)
@@ -469,6 +474,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
     std::lock_guard<std::mutex> lk(b->ctx->mtx);
     const size_t jobs = (size_t)b->n_channels * n_epochs;
     int max_len = 0;
+    float max_step = 0.0f;
     const std::vector<gc_stream*> rings = batch_streams(b);
     std::vector<uint64_t> floors(rings.size(), ~0ull), ends(rings.size(), 0);
     for (size_t j = 0; j < jobs; j++)
@@ -496,6 +502,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
                         (unsigned long long)p.sample_offset, p.n_samples, (unsigned long long)c.n_iq);
                 }
             if (p.n_samples > max_len) max_len = p.n_samples;
+            if (p.n_samples > 0) max_step = std::max(max_step, std::fabs(p.code_phase_step_chips) + std::fabs(p.code_phase_rate_step_chips) * (float)p.n_samples);
         }
     hipStream_t st = b->ctx->stream;
     if (jobs > b->params_cap)
@@ -515,7 +522,7 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
             b->out_cap = jobs * b->n_taps;
         }
     GC_HIP(hipMemcpyAsync(b->d_params, host_params, jobs * sizeof(gc_epoch_params), hipMemcpyHostToDevice, st));
-    gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len, &floors, &ends);
+    gc_status s = batch_launch(b, n_epochs, b->d_params, b->d_out, st, max_len, &floors, &ends, max_step);
     if (s != GC_OK) return s;
     // 16-bit mode: n_taps lv_16sc_t (4 bytes) per job instead of n_taps complex floats
     const size_t out_elem = b->sc16 ? sizeof(short2) : sizeof(float2);

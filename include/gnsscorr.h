@@ -278,8 +278,11 @@ gc_status gc_trk_batch_run(gc_trk_batch* b, int n_epochs, const gc_epoch_params*
  * gc_trk_batch_run_dev pick how many slices to cut an epoch into when the
  * batch alone would not fill the GPU, and size the LDS code window of a launch by what
  * one slice of such an epoch touches (long codes: Galileo E1's 8184 samples are cut in
- * two so that a workgroup holds half the table).  Results never depend on it: a record
- * outside the bound is served from the whole table.  set_slices(0) = automatic;
+ * two so that a workgroup holds half the table; gc_trk_batch_run_dev assumes ONE code period
+ * per nominal window, gc_trk_batch_run reads the code steps of its records).  Results never
+ * depend on it: a record outside the bound is served from the whole table, in LDS when the
+ * launch's LDS holds it, from global memory otherwise (slower: a batch of long codes whose
+ * windows span several code periods should use set_slices(-1)).  set_slices(0) = automatic;
  * set_slices(-1) = automatic slicing by load only, the window sized for the longest code
  * (the behaviour before round 4; A/B timing). */
 gc_status gc_trk_batch_set_nominal_length(gc_trk_batch* b, int n_samples);
@@ -552,7 +555,8 @@ gc_status gc_acq_get_grid(gc_acq* a, int sat, float* host_grid);
  * order whatever the layout in HBM).  `what`:
  *   GC_ACQ_PEEK_WIPEOFF   index = Doppler bin: the wipe-off row exp(-j phase) of the ACTIVE grid, d_grid_doppler_wipeoffs[bin]
  *                         (pcps_acquisition.cc:296-310), fft_size complex values = 2 * fft_size floats
- *   GC_ACQ_PEEK_SPECTRUM  index = Doppler bin: FFT(x * wipeoff[bin]) of the last dwell's block (:721), 2 * fft_size floats
+ *   GC_ACQ_PEEK_SPECTRUM  index = Doppler bin: FFT(x * wipeoff[bin]) of the last dwell's block (of the first block of a dwell
+ *                         pair processed together) (:721), 2 * fft_size floats
  *   GC_ACQ_PEEK_CODE      index = satellite slot: conj(FFT(code)) (d_fft_codes, :272-273), 2 * fft_size floats
  *   GC_ACQ_PEEK_ROW_MAX   index = satellite slot: per Doppler bin the maximum of the grid row and its position as the statistics
  *                         kernel sees them (the column pass's block maxima, combined): 2 * num_doppler_bins floats (value, index) */

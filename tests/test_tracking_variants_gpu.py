@@ -67,12 +67,28 @@ def test_launch_window_smaller_than_the_code_table(gctx, oracle):
         off = p["sample_offset"] + (3 if k == 1 else 0)
         recs.append(gnsscorr.epoch_params(off, float(p["rem_carr"]), float(p["phase_step"]), float(p["rem_code"]), steps[k], n))
         refs.append(oracle.multicorrelator(sig[off:], code, shifts, p["rem_carr"], p["phase_step"], p["rem_code"], np.float32(steps[k]), n))
-    got = _batch_one(gctx, sig, code, shifts, recs)
+    # device-resident records (gc_trk_batch_run_dev): the host knows only the nominal length, so the launch gets the small window; with a
+    # host-side array (gc_trk_batch_run) the engine reads the records' code steps and sizes the window for the largest
+    import torch
+    d_sig = torch.from_numpy(np.ascontiguousarray(sig).view(np.float32)).cuda()
+    d_par = torch.from_numpy(gnsscorr.epoch_params_array([recs]).view(np.uint8)).cuda()
+    d_out = torch.zeros(4 * 5, 2, dtype=torch.float32, device="cuda")
+    b = gnsscorr.TrackingBatch(gctx, 1, 5, len(code))
+    b.set_code(0, code, shifts)
+    b.set_input_dev(0, d_sig.data_ptr(), sig.size)
+    b.set_nominal_length(n)
+    torch.cuda.synchronize()
+    b.run_dev(4, d_par.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.complex64).reshape(4, 5)
+    b.close()
+    host = _batch_one(gctx, sig, code, shifts, recs)
     old = _batch_one(gctx, sig, code, shifts, recs, slices=-1)
     scale = abs(refs[0][2])
     assert scale > 0.5 * truth[0]["amp"] * n
     for k in range(4):
         assert np.max(np.abs(got[k] - refs[k])) <= TOL * scale, k
+        assert np.max(np.abs(host[k] - refs[k])) <= TOL * scale, k
         assert np.max(np.abs(old[k] - refs[k])) <= TOL * scale, k
     # the two nominal records are on the correlation peak; the others decorrelate (wrong chip rate / direction)
     assert abs(got[3][2]) > 0.5 * truth[0]["amp"] * n and abs(got[1][2]) < 0.1 * abs(got[0][2]) and abs(got[2][2]) < 0.1 * abs(got[0][2])

@@ -376,7 +376,7 @@ static gc_status batch_launch(gc_trk_batch* b, int n_epochs, const gc_epoch_para
     int lds_floats = b->lds_table_floats;
     const int len = max_len > 0 ? max_len : b->nominal_len;
     // (the high-dynamics resampler's window is the whole epoch whatever the slice: those modes keep the whole table)
-    if (len >= 4096 && b->lds_sizing && (b->mode == TRK_MODE_PLAIN || b->mode == TRK_MODE_COMPLEX_CODE))
+    if (len >= 4096 && b->lds_sizing && (b->mode == TRK_MODE_PLAIN || b->mode == TRK_MODE_COMPLEX_CODE) && trk_small_window_ok(b->mode, b->iq_format))
         {
             int l_max = 0;
             float spread = 0.0f;

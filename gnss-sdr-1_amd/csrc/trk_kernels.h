@@ -35,6 +35,7 @@ enum
 // line_aligned: the chunks of a window are counted from the 128-byte boundary below its first sample (whole cache lines per wave
 // instruction: the streaming launches) instead of the 16-byte one (the level-1 calls, whose staging keeps a window's 16-byte phase so
 // that a call gives the same bits alone and in a batch).
+bool trk_small_window_ok(int mode, int iq_format);
 hipError_t trk_launch(int n_taps, int mode, int iq_format, hipStream_t st, const TrkChan* chans,
     const gc_epoch_params* params, float2* out, float2* partial,
     int n_channels, int n_epochs, int n_slices, int lds_table_floats, bool line_aligned);

@@ -128,6 +128,18 @@ static size_t trk_chips_lds_bytes(int lds_table_floats)
     return (size_t)(TRK_HDR_FLOATS + ((lds_table_floats + 3) & ~3) + TRK_THREADS / 64 * TRK_CHIPS_WAVE_FLOATS) * sizeof(float);
 }
 #endif
+// whether trk_launch's kernel for (mode, format) serves records that fit neither the launch's LDS window nor the whole table in it
+// (the global-table path of trk_epoch): the host sizes a launch's LDS below the table only then
+bool trk_small_window_ok(int mode, int iq_format)
+{
+#ifdef GNSSCORR_EXPERIMENTS
+    if (mode == TRK_MODE_PLAIN && iq_format == GC_IQ_F32 && trk_chip_domain()) return false;  // the chip-domain loop keeps the whole table in LDS
+#endif
+    (void)mode;
+    (void)iq_format;
+    return true;
+}
+
 template <int NTAPS, int FMT>
 static hipError_t launch_ntaps_fmt(int mode, dim3 grid, size_t lds_bytes, hipStream_t st,
     const TrkChan* chans, const gc_epoch_params* params, float2* out, float2* partial,

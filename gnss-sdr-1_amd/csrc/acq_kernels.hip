@@ -21,6 +21,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
 
 #define ACQ_THREADS 256
 
@@ -376,6 +379,7 @@ struct AcqRows2Args
     int n_sats;  // satellites in this launch; cell = sat * n_bins + bin
     int n_groups;  // workgroups that have rows
     int sat_fastest;  // pair kernels: row order, 0 = (bin, sat, k1), 1 = (bin, k1, sat), 2 = (k1, bin, sat; planar kernel only)
+    unsigned long long* ts;  // ACQ_ROWS3_DBG builds, $GNSSCORR_ACQ_DBG & 64: six s_memrealtime stamps per workgroup (100 MHz)
     int dbg;          // $GNSSCORR_ACQ_DBG, timing experiments on acq_rows3_kernel only (results are WRONG with any bit set):
                       // 1 = no global input loads, 2 = no global stores, 4 = no twiddle loads, 8 = no butterflies
 };
@@ -911,6 +915,9 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
             }
         cell = sat * g.n_bins + bin;
     }
+#if ACQ_ROWS3_DBG
+    if ((g.dbg & 64) && g.ts && p == 0) g.ts[(size_t)group * 8 + 0] = __builtin_readcyclecounter() * 0 + wall_clock64();
+#endif
     PkC a[R], tw[R];
 #ifndef ACQ_ROWS3_HOIST_TW
 #define ACQ_ROWS3_HOIST_TW 0  // 1: the twiddle seeds of stages 2 and 3 are requested here, in front of the stage-1 inputs (loads return in order:
@@ -980,7 +987,13 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
             *reinterpret_cast<acq_f32x4*>(yi + 12) = acq_f32x4{a[2].i.y, a[3].i.y, a[4].i.y, a[5].i.y};
             *reinterpret_cast<acq_f32x4*>(yi + 16) = acq_f32x4{a[6].i.y, a[7].i.y, a[8].i.y, a[9].i.y};
         }
+#if ACQ_ROWS3_DBG
+    if ((g.dbg & 64) && g.ts && p == 0) g.ts[(size_t)group * 8 + 1] = __builtin_readcyclecounter() * 0 + wall_clock64();
+#endif
     __syncthreads();
+#if ACQ_ROWS3_DBG
+    if ((g.dbg & 64) && g.ts && p == 0) g.ts[(size_t)group * 8 + 2] = __builtin_readcyclecounter() * 0 + wall_clock64();
+#endif
     // ---- stage 2: S = 10, M = 10; butterflies u2 = 10 q + r, the pair shares q; inputs x[r + 10 q + 100 j] ----
     // Which pair of the row a lane takes in THIS stage is free (stage 1 wrote and stage 3 reads by position, not by owner).  With
     // consecutive lanes on consecutive r (q = lane / 5) the 8-byte stores of a 16-lane group fall into three 10-dword runs 100 dwords
@@ -1017,6 +1030,9 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
             }
         __syncthreads();
     }
+#if ACQ_ROWS3_DBG
+    if ((g.dbg & 64) && g.ts && p == 0) g.ts[(size_t)group * 8 + 3] = __builtin_readcyclecounter() * 0 + wall_clock64();
+#endif
     // ---- stage 3: S = 100, M = 1; r = u; inputs x[r + 100 j]; outputs n2 = r + 100 k with the inter-pass twiddle ----
     if (act)
         {
@@ -1044,6 +1060,9 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
             {
             pk_powers10(PkC{psplat(d.x), psplat(d.y)}, tw);
             const PkC bb = {acq_pk2{b.x, b.z}, acq_pk2{b.y, b.w}};
+#if ACQ_ROWS3_DBG
+            if ((g.dbg & 64) && g.ts && p == 0) g.ts[(size_t)group * 8 + 4] = __builtin_readcyclecounter() * 0 + wall_clock64();
+#endif
             float2* qp = g.Q + (size_t)cell * N + (size_t)k1 * N2 + u;
 #pragma unroll
             for (int k = 0; k < R; k++)
@@ -1057,7 +1076,14 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
                 }
             }
         }
+#if ACQ_ROWS3_DBG
+    if ((g.dbg & 64) && g.ts && p == 0) g.ts[(size_t)group * 8 + 5] = __builtin_readcyclecounter() * 0 + wall_clock64();
+#endif
     __syncthreads();  // stage 3 has read the planes: the next group's stage 1 may overwrite them
+#if ACQ_ROWS3_DBG
+    if ((g.dbg & 64) && g.ts && p == 0) g.ts[(size_t)group * 8 + 6] = __builtin_readcyclecounter() * 0 + wall_clock64();
+#endif
+
     }
 }
 
@@ -2495,6 +2521,20 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
                 return e ? std::atoi(e) : 0;
             }();
             g.dbg = dbg;
+#if ACQ_ROWS3_DBG
+            static unsigned long long* d_ts = nullptr;
+            static size_t ts_cap = 0;
+            if ((dbg & 64) && inverse)
+                {
+                    if (ts_cap < (size_t)g.n_groups * 8)
+                        {
+                            (void)hipFree(d_ts);
+                            ts_cap = (size_t)g.n_groups * 8;
+                            (void)hipMalloc(&d_ts, ts_cap * sizeof(unsigned long long));
+                        }
+                    g.ts = d_ts;
+                }
+#endif
             static const int persist = [] {
                 const char* e = gc_exp_env("GNSSCORR_ACQ_PERSIST");  // workgroups per CU of the persistent row launch (0: one block per group)
                 return e ? std::atoi(e) : 0;  // measured: with the (bin, k1, sat) order 4 per CU (what the LDS admits) was 2 % faster than a block per group,
@@ -2505,6 +2545,32 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
                     const unsigned cap = (unsigned)(persist * 256);
                     if (grid2.x > cap) grid2.x = cap;
                 }
+#if ACQ_ROWS3_DBG
+            if ((dbg & 64) && inverse && g.ts)
+                {
+                    // TIMING EXPERIMENT: run the launch, fetch the stamps, print where a workgroup's lifetime goes (synchronises the device)
+                    hipError_t el = hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);
+                    (void)hipDeviceSynchronize();
+                    static int printed = 0;
+                    if (printed++ % 40 == 39)
+                        {
+                            std::vector<unsigned long long> h((size_t)g.n_groups * 8);
+                            (void)hipMemcpy(h.data(), g.ts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                            double sum[6] = {0, 0, 0, 0, 0, 0};
+                            unsigned long long tmin = ~0ull, tmax = 0;
+                            for (int i = 0; i < g.n_groups; i++)
+                                {
+                                    const unsigned long long* t = &h[(size_t)i * 8];
+                                    for (int k = 0; k < 6; k++) sum[k] += (double)(t[k + 1] - t[k]);
+                                    tmin = std::min(tmin, t[0]);
+                                    tmax = std::max(tmax, t[6]);
+                                }
+                            std::fprintf(stderr, "rows3 stamps (10 ns ticks, mean over %d workgroups): inputs+stage1 %.0f | barrier1 %.0f | stage2 %.0f | stage3 to stores %.0f | stores issue %.0f | last barrier %.0f ; kernel span %.0f\n",
+                                g.n_groups, sum[0] / g.n_groups, sum[1] / g.n_groups, sum[2] / g.n_groups, sum[3] / g.n_groups, sum[4] / g.n_groups, sum[5] / g.n_groups, (double)(tmax - tmin));
+                        }
+                    return el;
+                }
+#endif
             return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);
         }
     dim3 grid(plan.N1, n_cells);

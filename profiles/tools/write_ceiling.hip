@@ -8,6 +8,56 @@
 #include <cstdlib>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// a workgroup that computes for a while (FMAS dependent v_fma_f32 per thread on 8 independent chains: no memory, no LDS traffic) and THEN
+// stores its 40 KB: does the chip overlap the stores of some workgroups with the arithmetic of others at 4 workgroups per CU?
+template <int FMAS, bool STORE>
+__global__ __launch_bounds__(256) void compute_then_store(f4* __restrict__ Q, int n_groups, float seed)
+{
+    extern __shared__ float lds[];
+    const int per_xcd = gridDim.x >> 3;
+    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (group >= n_groups) return;
+    const int p = threadIdx.x;
+    if (p >= 250) return;
+    const int row = p / 50, u = p - row * 50;
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = seed + (float)(p + i);
+    for (int it = 0; it < FMAS / 8; it++)
+        {
+#pragma unroll
+            for (int i = 0; i < 8; i++) c[i] = fmaf(c[i], 1.0000001f, 0.5f);
+        }
+    f4* q = Q + ((size_t)group * 5 + row) * 500 + u;
+    if (STORE)
+        {
+#pragma unroll
+            for (int k = 0; k < 10; k++) q[50 * k] = f4{c[k & 7], c[(k + 1) & 7], c[(k + 2) & 7], c[(k + 3) & 7]};
+        }
+    else if (c[0] == 1.2345e-30f)
+        q[0] = f4{c[0], c[1], c[2], c[3]};
+    if (lds[0] == 1.2345e-30f) q[0] = f4{c[4], c[5], c[6], c[7]};
+}
+
+template <int FMAS, bool STORE>
+static void run_cs(const char* name, f4* Q, int n_groups, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const unsigned grid = (unsigned)((n_groups + 7) / 8 * 8);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((compute_then_store<FMAS, STORE>), dim3(grid), dim3(256), lds_bytes, 0, Q, n_groups, 0.25f);
+    (void)hipDeviceSynchronize();
+    const int reps = 20;
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((compute_then_store<FMAS, STORE>), dim3(grid), dim3(256), lds_bytes, 0, Q, n_groups, 0.25f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::printf("%-60s lds %5d B/wg: %6.2f us per launch\n", name, lds_bytes, ms * 1e3 / reps);
+}
+
 template <bool LOADS, bool NT>
 __global__ __launch_bounds__(256) void rows_traffic(const f4* __restrict__ A, const f4* __restrict__ B, f4* __restrict__ Q, int n_groups)
 {
@@ -79,6 +129,20 @@ int main()
             run<false, true>("stores only, nontemporal", A, B, Q, n_groups, lds);
             run<true, false>("2 x 40 KB cached loads + stores", A, B, Q, n_groups, lds);
             run<true, true>("2 x 40 KB cached loads + nontemporal stores", A, B, Q, n_groups, lds);
+        }
+    // arithmetic and stores of DIFFERENT workgroups: sum or maximum?
+    for (int lds : {40000, 20000})
+        {
+            run_cs<1200, false>("1200 fma per thread, no stores", Q, n_groups, lds);
+            run_cs<1200, true>("1200 fma per thread, then 40 KB of stores per workgroup", Q, n_groups, lds);
+            run_cs<1600, false>("1600 fma per thread, no stores", Q, n_groups, lds);
+            run_cs<1600, true>("1600 fma per thread, then 40 KB of stores per workgroup", Q, n_groups, lds);
+            run_cs<2000, false>("2000 fma per thread, no stores", Q, n_groups, lds);
+            run_cs<2000, true>("2000 fma per thread, then 40 KB of stores per workgroup", Q, n_groups, lds);
+            run_cs<3200, false>("3200 fma per thread, no stores", Q, n_groups, lds);
+            run_cs<3200, true>("3200 fma per thread, then 40 KB of stores per workgroup", Q, n_groups, lds);
+            run_cs<6400, false>("6400 fma per thread, no stores", Q, n_groups, lds);
+            run_cs<6400, true>("6400 fma per thread, then 40 KB of stores per workgroup", Q, n_groups, lds);
         }
     return 0;
 }

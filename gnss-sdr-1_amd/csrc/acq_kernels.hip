@@ -2565,6 +2565,14 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
                                     tmin = std::min(tmin, t[0]);
                                     tmax = std::max(tmax, t[6]);
                                 }
+                            if (const char* tf = std::getenv("GNSSCORR_ACQ_TS_FILE"))
+                                {
+                                    if (FILE* f = std::fopen(tf, "wb"))
+                                        {
+                                            std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+                                            std::fclose(f);
+                                        }
+                                }
                             std::fprintf(stderr, "rows3 stamps (10 ns ticks, mean over %d workgroups): inputs+stage1 %.0f | barrier1 %.0f | stage2 %.0f | stage3 to stores %.0f | stores issue %.0f | last barrier %.0f ; kernel span %.0f\n",
                                 g.n_groups, sum[0] / g.n_groups, sum[1] / g.n_groups, sum[2] / g.n_groups, sum[3] / g.n_groups, sum[4] / g.n_groups, sum[5] / g.n_groups, (double)(tmax - tmin));
                         }

@@ -1087,8 +1087,11 @@ static __device__ __forceinline__ void acq_rows3_body(const AcqFftPlan& plan, co
     }
 }
 
+#ifndef ACQ_ROWS3_THREADS
+#define ACQ_ROWS3_THREADS 256  // 512: ten rows per workgroup (80 KB of LDS, two workgroups per CU), half as many workgroups to dispatch
+#endif
 template <bool INV>
-__global__ __launch_bounds__(ACQ_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
+__global__ __launch_bounds__(ACQ_ROWS3_THREADS, ACQ_ROWS3_WAVES) void acq_rows3_kernel(AcqFftPlan plan, AcqRows2Args g)
 {
     extern __shared__ float2 sm[];
     acq_rows3_body<INV>(plan, g, sm, blockIdx.x & 7, blockIdx.x >> 3, gridDim.x >> 3);
@@ -2577,6 +2580,23 @@ hipError_t acq_launch_rows(hipStream_t st, bool inverse, const AcqFftPlan& plan,
                                 g.n_groups, sum[0] / g.n_groups, sum[1] / g.n_groups, sum[2] / g.n_groups, sum[3] / g.n_groups, sum[4] / g.n_groups, sum[5] / g.n_groups, (double)(tmax - tmin));
                         }
                     return el;
+                }
+#endif
+#if ACQ_ROWS3_THREADS != 256
+            if (fn == (inverse ? reinterpret_cast<AcqRows2Fn>(&acq_rows3_kernel<true>) : reinterpret_cast<AcqRows2Fn>(&acq_rows3_kernel<false>)))
+                {
+                    g.rpw *= ACQ_ROWS3_THREADS / 256;
+                    g.n_groups = (g.n_rows + g.rpw - 1) / g.rpw;
+                    const dim3 grid3((unsigned)((g.n_groups + 7) / 8 * 8));
+                    const size_t lds3 = (size_t)g.rpw * plan.N2 * sizeof(float2);
+                    static bool attr_set[2] = {false, false};
+                    if (!attr_set[inverse ? 1 : 0])
+                        {
+                            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                            if (ea != hipSuccess) return ea;
+                            attr_set[inverse ? 1 : 0] = true;
+                        }
+                    return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid3, dim3(ACQ_ROWS3_THREADS), args, lds3, st);
                 }
 #endif
             return hipLaunchKernel(reinterpret_cast<const void*>(fn), grid2, dim3(ACQ_THREADS), args, lds2, st);

@@ -819,7 +819,9 @@ def main():
                                       "the slowest of the three concurrent engines sets the floor"}
             extra["closed_loop_cfg5_share"] = {"channels": 32, "ms_of_signal": ms_total, "ms": share_ms, "realtime_factor": ms_total / share_ms, "roofline": share_roof,
                 "note": "16 GPS L1 C/A + 8 Galileo E1 (5 taps, 4 ms) + 8 BeiDou B1I channels x 25 Msps in closed loop, three engines on three "
-                        "streams, one 1024-thread workgroup per channel, host wall time of the three run_dev calls (launch-inclusive).  A code "
+                        "streams, one 1024-thread workgroup per channel, host wall time of the three run_dev calls (launch-inclusive).  DEPENDS ON "
+                        "GPU_MAX_HW_QUEUES >= 6 in the process environment before HIP initialises (this script sets 8, see runtime_env): with the "
+                        "runtime's default of 4 hardware queues two engines share one and run one after the other (47x).  A code "
                         "period costs ~11 us whatever the channel count (7.5 correlation by one CU + 2.6 one-lane loop maths): cutting periods "
                         "into slices over more CUs was built and measured slower (13.4 us: experiments build, DESIGN.md appendix A)"}
 
